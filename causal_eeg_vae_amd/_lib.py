@@ -1,0 +1,91 @@
+"""ctypes binding of libceeg.so (include/ceeg.h) — the only way the package reaches the GPU kernels.
+
+There is NO CPU fallback: if the shared library is missing or the call fails, this raises.  PyTorch is
+used only for device memory (tensors own every buffer, workspaces included) and the current stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libceeg.so")
+
+CEEG_F32, CEEG_BF16 = 0, 1
+
+_c_i64, _c_int, _c_f32, _c_u64, _c_sz, _vp = C.c_int64, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/ceeg.h one to one
+SIGNATURES = {
+    "ceeg_version": (_c_int, []),
+    "ceeg_strerror": (C.c_char_p, [_c_int]),
+    "ceeg_check_device": (_c_int, []),
+    "ceeg_vq_forward_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
+    "ceeg_vq_forward": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_vq_backward_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
+    "ceeg_vq_backward": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_csr_build_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
+    "ceeg_csr_build": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_csr_transpose_ws_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "ceeg_csr_transpose": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_gcn_norm": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp]),
+    "ceeg_spmm_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
+    "ceeg_spmm_csr": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_reparam_kl_ws_bytes": (_c_sz, [_c_i64, _c_int]),
+    "ceeg_reparam_kl_fwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _c_i64, _c_int, _c_f32, _c_int, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_reparam_kl_bwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _vp, _vp, _c_i64, _c_int, _c_f32, _c_int, _c_int, _vp, _c_i64, _vp, _c_i64, _vp]),
+    "ceeg_edge_bce_ws_bytes": (_c_sz, [_c_i64, _c_int]),
+    "ceeg_edge_bce_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_decoder_fused_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
+    "ceeg_decoder_fused_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_decoder_fused_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class CeegError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libceeg.so (once).  Raises CeegError when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise CeegError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(make -C causal_eeg_vae_amd/csrc).  The HIP extension is required; there is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise CeegError(f"{what} failed: {lib().ceeg_strerror(rc).decode()} (code {rc})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous where the ABI says so."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def workspace(nbytes, device):
+    """Caller-owned workspace: a uint8 tensor from torch's caching allocator (256-byte aligned)."""
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise CeegError("causal_eeg_vae_amd runs on MI355X (ROCm) tensors only; got a CPU tensor. "
+                            "There is no CPU fallback in the product path (the CPU oracle lives under oracle/ for tests).")

@@ -1,0 +1,91 @@
+// Shared device/host helpers for libceeg.so (gfx950 / CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ceeg.h"
+
+#define CEEG_WAVE 64
+
+#define CEEG_CHECK_LAUNCH()                          \
+  do {                                               \
+    if (hipGetLastError() != hipSuccess) return CEEG_ELAUNCH; \
+  } while (0)
+
+static inline size_t ceeg_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline bool ceeg_aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+// Bump allocator over the caller's workspace (256-byte aligned carves). Host-side only.
+struct CeegWs {
+  char* base;
+  size_t off, cap;
+  bool ok;
+  CeegWs(void* p, size_t bytes) : base(static_cast<char*>(p)), off(0), cap(bytes), ok(true) {}
+  template <class T>
+  T* take(size_t n) {
+    size_t need = ceeg_align_up(n * sizeof(T), 256);
+    if (base == nullptr || off + need > cap) { ok = false; return nullptr; }
+    T* r = reinterpret_cast<T*>(base + off);
+    off += need;
+    return r;
+  }
+};
+static inline size_t ceeg_ws_part(size_t n, size_t elem) { return ceeg_align_up(n * elem, 256); }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float ceeg_bf16_to_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN kept a NaN)
+__device__ __forceinline__ unsigned short ceeg_f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+__device__ __forceinline__ float ceeg_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;  // fixed butterfly order: identical in every lane, reproducible
+}
+__device__ __forceinline__ double ceeg_wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Philox4x32-10, restated bit for bit in oracle/ceeg_oracle.c
+#define CEEG_TAG_EPS 0x45505300u
+#define CEEG_TAG_NEG 0x4E454700u
+__device__ __forceinline__ uint4 ceeg_philox(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return make_uint4(c0, c1, c2, c3);
+}
+// two uint32 -> two N(0,1) (Box-Muller); u = (x+1)*2^-32 in (0,1]
+__device__ __forceinline__ float2 ceeg_box_muller(uint32_t x0, uint32_t x1) {
+  float u0 = ((float)x0 + 1.0f) * 2.3283064365386963e-10f;
+  float u1 = ((float)x1 + 1.0f) * 2.3283064365386963e-10f;
+  u0 = fminf(u0, 1.0f);
+  float r = sqrtf(-2.0f * logf(u0));
+  float t = 6.283185307179586f * u1;
+  float s, c;
+  sincosf(t, &s, &c);
+  return make_float2(r * c, r * s);
+}
+
+// ---------------------------------------------------------------- internal cross-file launchers
+// Extra addressing for the SpMM used by the fused decoder backward: affine (bijective) maps on the
+// gathered column index and on the output row, and a device-side scale applied to the row sum.
+struct CeegSpmmEx {
+  int64_t row_a = 1, row_b = 0, col_a = 1, col_b = 0, mod = 1;
+  const float* scale = nullptr;
+};
+int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                     const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                     int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
+                     const CeegSpmmEx& ex);

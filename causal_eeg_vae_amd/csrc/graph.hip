@@ -1,0 +1,274 @@
+// Graph structure kernels: edge list -> canonical CSR (by dst, then src, then edge id), its transpose,
+// gcn_norm values, and the uniform negative sampler.
+//
+// Stands behind upstream PyG gcn_norm / add_remaining_self_loops / negative_sampling (un-vendored,
+// unpinned: /root/reference/environment.yml:13); edge direction as built at scripts/dataset.py:147-153.
+// The (dst, src, edge id) ordering is a stable LSD radix sort of 64-bit keys (rocPRIM device radix sort,
+// header-only, compiled into this library; temporary storage comes from the caller's workspace).
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "ceeg_internal.h"
+
+namespace {
+
+constexpr uint64_t KEY_INVALID = ~0ull;
+
+__global__ void csr_edge_keys_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int64_t N,
+                                     int self_loops, uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                     int32_t* __restrict__ loop_eid) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = src[e], d = dst[e];
+  uint64_t key = KEY_INVALID;
+  if (s >= 0 && s < N && d >= 0 && d < N) {
+    if (self_loops && s == d) {
+      atomicMax(&loop_eid[s], (int32_t)e);  // integer max: order-independent -> deterministic
+    } else {
+      key = ((uint64_t)d << 32) | (uint64_t)s;
+    }
+  }
+  keys[e] = key;
+  vals[e] = (int32_t)e;
+}
+
+__global__ void csr_loop_keys_kernel(int64_t E, int64_t N, uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+                                     const int32_t* __restrict__ loop_eid) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  keys[E + i] = ((uint64_t)i << 32) | (uint64_t)i;
+  vals[E + i] = loop_eid[i];  // last existing self-loop's edge id (its weight survives) or -1
+}
+
+// sorted keys -> rowptr / col / perm.  Thread p closes every row between key[p-1] and key[p].
+__global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t M, int64_t N,
+                                  int32_t* __restrict__ rowptr, int32_t* __restrict__ col, int32_t* __restrict__ perm,
+                                  int64_t* __restrict__ nnz_out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  int64_t d_cur = N, d_prev = -1;
+  if (p < M) {
+    const uint64_t k = keys[p];
+    const int64_t d = (int64_t)(k >> 32);
+    d_cur = d < N ? d : N;
+    if (d < N) {
+      col[p] = (int32_t)(k & 0xffffffffu);
+      perm[p] = vals[p];
+    }
+  }
+  if (p > 0) {
+    const int64_t d = (int64_t)(keys[p - 1] >> 32);
+    d_prev = d < N ? d : N;
+  }
+  for (int64_t r = d_prev + 1; r <= d_cur; ++r) {
+    rowptr[r] = (int32_t)p;
+    if (r == N && nnz_out) *nnz_out = p;
+  }
+}
+
+// entry p of row r -> key (col[p] << 32 | r), value p
+__global__ void csr_transpose_keys_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
+                                          uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per row
+  if (r >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  for (int p = lo + lane; p < hi; p += 64) {
+    keys[p] = ((uint64_t)(uint32_t)col[p] << 32) | (uint64_t)r;
+    vals[p] = p;
+  }
+}
+
+__global__ void gcn_deg_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, const float* __restrict__ ew,
+                               int64_t N, float* __restrict__ dinv) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= N) return;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  float deg;
+  if (ew == nullptr) {
+    deg = (float)(hi - lo);
+  } else {
+    deg = 0.f;
+    for (int p = lo; p < hi; ++p) {  // sequential, p ascending: reproducible
+      const int e = perm[p];
+      deg += e >= 0 ? ew[e] : 1.0f;
+    }
+  }
+  dinv[r] = deg > 0.f ? 1.0f / sqrtf(deg) : 0.f;
+}
+
+__global__ void gcn_val_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
+                               const float* __restrict__ ew, const float* __restrict__ dinv, int64_t N, float* __restrict__ val) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  const float dr = dinv[r];
+  for (int p = lo + lane; p < hi; p += 64) {
+    float w = 1.0f;
+    if (ew) { const int e = perm[p]; w = e >= 0 ? ew[e] : 1.0f; }
+    val[p] = dinv[col[p]] * w * dr;
+  }
+}
+
+__device__ __forceinline__ bool csr_has(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t d, int32_t s) {
+  int lo = rowptr[d];
+  const int end = rowptr[d + 1];
+  int hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  return lo < end && col[lo] == s;
+}
+
+__global__ void neg_sample_uniform_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int64_t num,
+                                          uint64_t seed, int32_t* __restrict__ neg_src, int32_t* __restrict__ neg_dst) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= num) return;
+  int32_t s = -1, d = -1;
+  for (uint32_t a = 0; a < 16; ++a) {  // bounded: every lane leaves after at most 16 attempts
+    const uint4 x = ceeg_philox(seed, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), CEEG_TAG_NEG, a);
+    const int32_t cs = (int32_t)(((uint64_t)x.x * (uint64_t)N) >> 32);
+    const int32_t cd = (int32_t)(((uint64_t)x.y * (uint64_t)N) >> 32);
+    if (cs == cd) continue;
+    if (csr_has(rowptr, col, cd, cs)) continue;
+    s = cs; d = cd;
+    break;
+  }
+  neg_src[k] = s;
+  neg_dst[k] = d;
+}
+
+unsigned key_bits(int64_t N) {  // bits needed for the value N itself (so all-ones > any valid node id)
+  unsigned b = 1;
+  while (((int64_t)1 << b) <= N) ++b;
+  return b;
+}
+
+size_t sort_temp_bytes(size_t M, unsigned end_bit) {
+  size_t bytes = 0;
+  uint64_t* k = nullptr;
+  int32_t* v = nullptr;
+  hipError_t e = rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, M, 0u, end_bit, (hipStream_t)0, false);
+  if (e != hipSuccess) return 0;
+  return bytes;
+}
+
+struct SortWs {
+  uint64_t *keys_in, *keys_out;
+  int32_t *vals_in, *vals_out, *loop_eid;
+  void* temp;
+  size_t temp_bytes;
+};
+size_t sort_layout(int64_t M, int64_t N, unsigned end_bit, void* ws, size_t ws_bytes, SortWs* out) {
+  const size_t tb = sort_temp_bytes((size_t)M, end_bit);
+  if (tb == 0 && M > 0) return 0;
+  size_t need = 2 * ceeg_ws_part(M, 8) + 2 * ceeg_ws_part(M, 4) + ceeg_ws_part(N, 4) + ceeg_align_up(tb, 256);
+  if (out) {
+    CeegWs a(ws, ws_bytes);
+    out->keys_in = a.take<uint64_t>(M);
+    out->keys_out = a.take<uint64_t>(M);
+    out->vals_in = a.take<int32_t>(M);
+    out->vals_out = a.take<int32_t>(M);
+    out->loop_eid = a.take<int32_t>(N);
+    out->temp = a.take<char>(tb);
+    out->temp_bytes = tb;
+    if (!a.ok) return 0;
+  }
+  return need;
+}
+
+}  // namespace
+
+extern "C" size_t ceeg_csr_build_ws_bytes(int64_t E, int64_t N, int self_loops) {
+  if (E < 0 || N <= 0) return 0;
+  const int64_t M = E + (self_loops ? N : 0);
+  return sort_layout(M, N, 32 + key_bits(N), nullptr, 0, nullptr);
+}
+
+extern "C" int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int self_loops,
+                              int32_t* rowptr, int32_t* col, int32_t* perm, int64_t* nnz_out,
+                              void* ws, size_t ws_bytes, void* stream) {
+  if (E < 0 || N <= 0 || !rowptr || (E > 0 && (!src || !dst))) return CEEG_EINVAL;
+  const int64_t M = E + (self_loops ? N : 0);
+  if (M > 0 && (!col || !perm)) return CEEG_EINVAL;
+  if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned end_bit = 32 + key_bits(N);
+  SortWs w;
+  const size_t need = sort_layout(M, N, end_bit, nullptr, 0, nullptr);
+  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (sort_layout(M, N, end_bit, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  if (self_loops) {
+    if (hipMemsetAsync(w.loop_eid, 0xff, (size_t)N * 4, st) != hipSuccess) return CEEG_ELAUNCH;
+  }
+  if (E > 0) {
+    hipLaunchKernelGGL(csr_edge_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, E, N, self_loops,
+                       w.keys_in, w.vals_in, w.loop_eid);
+    CEEG_CHECK_LAUNCH();
+  }
+  if (self_loops) {
+    hipLaunchKernelGGL(csr_loop_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, E, N, w.keys_in, w.vals_in, w.loop_eid);
+    CEEG_CHECK_LAUNCH();
+  }
+  size_t tb = w.temp_bytes;
+  if (M > 0) {
+    if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)M, 0u, end_bit, st, false) != hipSuccess)
+      return CEEG_ELAUNCH;
+  }
+  hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, M, N, rowptr, col,
+                     perm, nnz_out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" size_t ceeg_csr_transpose_ws_bytes(int64_t nnz, int64_t N) {
+  if (nnz < 0 || N <= 0) return 0;
+  return sort_layout(nnz, N, 32 + key_bits(N), nullptr, 0, nullptr);
+}
+
+extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, int64_t N,
+                                  int32_t* t_rowptr, int32_t* t_col, int32_t* t_perm,
+                                  void* ws, size_t ws_bytes, void* stream) {
+  if (nnz < 0 || N <= 0 || !rowptr || !t_rowptr || (nnz > 0 && (!col || !t_col || !t_perm))) return CEEG_EINVAL;
+  if (N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const unsigned end_bit = 32 + key_bits(N);
+  SortWs w;
+  const size_t need = sort_layout(nnz, N, end_bit, nullptr, 0, nullptr);
+  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (sort_layout(nnz, N, end_bit, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  hipLaunchKernelGGL(csr_transpose_keys_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in);
+  CEEG_CHECK_LAUNCH();
+  size_t tb = w.temp_bytes;
+  if (nnz > 0) {
+    if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)nnz, 0u, end_bit, st, false) != hipSuccess)
+      return CEEG_ELAUNCH;
+  }
+  hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((nnz + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, nnz, N, t_rowptr,
+                     t_col, t_perm, (int64_t*)nullptr);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew,
+                             int64_t nnz, int64_t N, float* deg_inv_sqrt, float* val, void* stream) {
+  if (N <= 0 || nnz < 0 || !rowptr || !deg_inv_sqrt || (nnz > 0 && (!col || !val)) || (ew && !perm)) return CEEG_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(gcn_deg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, rowptr, perm, ew, N, deg_inv_sqrt);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gcn_val_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, perm, ew, deg_inv_sqrt, N, val);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_neg_sample_uniform(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
+                                       int32_t* neg_src, int32_t* neg_dst, void* stream) {
+  if (N <= 1 || num < 0 || !rowptr || !col || (num > 0 && (!neg_src || !neg_dst))) return CEEG_EINVAL;
+  if (num == 0) return CEEG_OK;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(neg_sample_uniform_kernel, dim3((unsigned)((num + 255) / 256)), dim3(256), 0, st, rowptr, col, N, num, seed, neg_src,
+                     neg_dst);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}

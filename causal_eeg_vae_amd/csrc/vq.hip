@@ -1,0 +1,803 @@
+// VectorQuantizer forward/backward for gfx950 (MI355X).
+//
+// Stands behind scripts/quantizer.py:25-67 (reference) — see include/ceeg.h for the contract.
+//
+// Forward = 4 launches on the caller's stream:
+//   vq_prep_kernel   : ee[c] (fp32: |W_c|^2 fmaf chain; bf16: -|bf16(W_c)|^2/2) + the codebook image in
+//                      exactly the (XOR-swizzled) order the main kernel wants in LDS        (tiny)
+//   vq_main_*        : distance GEMM on MFMA + running argmin in registers + codebook-row gather
+//                      (z_q), squared error partial per block, idx                          (dominant)
+//   vq_hist_kernel   : per-slice integer histograms of idx in LDS -> partial table (no atomics in HBM)
+//   vq_finalize      : fixed-order reduction -> loss, perplexity, hist
+//
+// MFMA mapping (16x16 output tiles; C/D: col = lane&15 = code, row = 4*(lane>>4)+reg = latent row):
+//   fp32 : v_mfma_f32_16x16x4_f32, A lane(r,q) = z[r][4s+q], B lane(c,q) = W[c][4s+q]; one accumulator
+//          chain per (row tile), k ascending from 0 => dot is the sequential fmaf chain of the oracle.
+//   bf16 : v_mfma_f32_16x16x32_bf16, A lane(r,q) = z[r][32s+8q .. +8], B likewise from the codebook;
+//          C is seeded with -ee/2 so the accumulator IS the score (no epilogue arithmetic).
+// The codebook is streamed through LDS in chunks of CT codes; z tiles live in registers for the whole
+// kernel (each z element is read from HBM exactly once).
+#include "ceeg_internal.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+namespace {
+
+constexpr int VQ_WAVES = 4;        // waves per block
+constexpr int VQ_THREADS = VQ_WAVES * 64;
+constexpr int VQ_HIST_ROWS = 4096; // rows per histogram slice
+constexpr int VQ_SEG = 256;        // sorted rows per backward chunk
+
+__host__ __device__ constexpr int vq_min(int a, int b) { return a < b ? a : b; }
+
+// ------------------------------------------------------------------------------------------ prep
+// ee / image.  One thread per code computes the norm chain; all threads then write image elements.
+template <bool BF16>
+__global__ void vq_prep_kernel(const float* __restrict__ W, int n_e, int D, int n_ep, int DP,
+                               float* __restrict__ ee, void* __restrict__ img) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < n_ep) {
+    const int c = (int)tid;
+    float e;
+    if (c < n_e) {
+      e = 0.f;
+      for (int k = 0; k < D; ++k) {
+        float w = W[(size_t)c * D + k];
+        if (BF16) w = ceeg_bf16_to_f32(ceeg_f32_to_bf16(w));
+        e = __fmaf_rn(w, w, e);
+      }
+      if (BF16) e = -0.5f * e;
+    } else {
+      e = BF16 ? -INFINITY : INFINITY;  // padded codes can never win
+    }
+    ee[c] = e;
+  }
+  const int64_t total = (int64_t)n_ep * DP;
+  for (int64_t i = tid; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / DP), k = (int)(i % DP);
+    const float w = (c < n_e && k < D) ? W[(size_t)c * D + k] : 0.f;
+    if (BF16) {
+      const int cpr = DP / 8;                       // 16-byte chunks per row
+      const int swz = c & (vq_min(16, cpr) - 1);
+      const int chunk = k >> 3;
+      reinterpret_cast<unsigned short*>(img)[(size_t)c * DP + ((chunk ^ swz) << 3) + (k & 7)] = ceeg_f32_to_bf16(w);
+    } else {
+      const int q = k & 3, s = k >> 2;              // de-interleave by k mod 4 (the MFMA's k index)
+      const int cpq = DP / 16;                      // 16-byte chunks per quarter row
+      const int swz = c & (vq_min(16, cpq) - 1);
+      const int chunk = s >> 2, e = s & 3;
+      reinterpret_cast<float*>(img)[(size_t)c * DP + q * (DP / 4) + ((chunk ^ swz) << 2) + e] = w;
+    }
+  }
+}
+
+__device__ __forceinline__ float pick4(const float4& v, int q) {
+  return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+}
+
+// block-level fixed-order sum of one float per thread -> result valid in thread 0
+__device__ __forceinline__ float vq_block_sum(float v, float* red /* [VQ_WAVES] LDS */) {
+  v = ceeg_wave_sum(v);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) red[wave] = v;
+  __syncthreads();
+  float t = 0.f;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < VQ_WAVES; ++w) t += red[w];
+  }
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------ fp32 main
+// EXACT: D == DP (every 16-byte access is in bounds and aligned).  Otherwise the ragged tail is handled
+// with clamped scalar loads + selects (branch-free) and guarded scalar stores.
+template <int DP, bool EXACT>
+__global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
+    const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ ee,
+    const float* __restrict__ img, int64_t B, int n_e, int D, int n_ep,
+    float* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
+  constexpr int RT = 2;                 // 16-row tiles per wave
+  constexpr int ROWS_W = RT * 16;       // rows per wave
+  constexpr int BM = VQ_WAVES * ROWS_W; // rows per block
+  constexpr int CT = 32;                // codes per LDS stage
+  constexpr int NU = DP / 4;            // float4 per row == MFMA k-steps
+  constexpr int CPQ = DP / 16;
+  constexpr int SWZ_MASK = vq_min(16, CPQ) - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* lds_w = reinterpret_cast<float*>(smem);                 // [CT][DP]
+  int* lds_idx = reinterpret_cast<int*>(smem + CT * DP * 4);     // [BM]
+  float* lds_red = reinterpret_cast<float*>(smem + CT * DP * 4 + BM * 4);  // [VQ_WAVES]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * BM + wave * ROWS_W;
+
+  // ---- z tile -> registers: lane (r,q) keeps z[r][4u+q] (the MFMA A operand of k-step u), loaded as
+  // dwords (16 rows x 16 B per wave-instruction; the kernel is MFMA-bound by >10x, L1 absorbs it).
+  // zz[r] is the natural-order fmaf chain over the whole row, computed redundantly by the row's 4 lanes.
+  // Rows past B are clamped to B-1 for the loads (their results are never stored).
+  float a[RT][NU];
+  float zz[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int64_t row = row0 + rt * 16 + r;
+    row = row < B ? row : B - 1;
+    const float* zr = z + row * D;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if constexpr (EXACT) {
+        a[rt][u] = zr[4 * u + q];
+      } else {
+        const int k = 4 * u + q;
+        const float t = zr[k < D ? k : D - 1];
+        a[rt][u] = k < D ? t : 0.f;
+      }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      float4 v;
+      if constexpr (EXACT) {
+        v = *reinterpret_cast<const float4*>(zr + 4 * u);
+      } else {
+        const int k = 4 * u, dm = D - 1;
+        v.x = zr[k + 0 < D ? k + 0 : dm]; v.x = k + 0 < D ? v.x : 0.f;
+        v.y = zr[k + 1 < D ? k + 1 : dm]; v.y = k + 1 < D ? v.y : 0.f;
+        v.z = zr[k + 2 < D ? k + 2 : dm]; v.z = k + 2 < D ? v.z : 0.f;
+        v.w = zr[k + 3 < D ? k + 3 : dm]; v.w = k + 3 < D ? v.w : 0.f;
+      }
+      acc = __fmaf_rn(v.x, v.x, acc);
+      acc = __fmaf_rn(v.y, v.y, acc);
+      acc = __fmaf_rn(v.z, v.z, acc);
+      acc = __fmaf_rn(v.w, v.w, acc);
+      if ((u & 7) == 7) asm volatile("" ::: "memory");  // keep <= 8 float4 loads in flight (register budget)
+    }
+    zz[rt] = acc;  // identical in the 4 q-lanes of row r
+  }
+  // zz of the rows this lane owns in the C layout (row = 4q + i)
+  float zzc[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) zzc[rt][i] = __shfl(zz[rt], 4 * q + i, 64);
+
+  float best[RT][4];
+  int bidx[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { best[rt][i] = INFINITY; bidx[rt][i] = 0; }
+
+  const int nch = n_ep / CT;
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();  // previous chunk fully consumed
+    {
+      const float4* src = reinterpret_cast<const float4*>(img + (size_t)ch * CT * DP);
+      float4* dst = reinterpret_cast<float4*>(lds_w);
+#pragma unroll
+      for (int i = 0; i < CT * DP / 4 / VQ_THREADS; ++i) dst[i * VQ_THREADS + threadIdx.x] = src[i * VQ_THREADS + threadIdx.x];
+      if constexpr ((CT * DP / 4) % VQ_THREADS != 0) {
+        const int i = (CT * DP / 4 / VQ_THREADS) * VQ_THREADS + threadIdx.x;
+        if (i < CT * DP / 4) dst[i] = src[i];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CT / 16; ++ct) {
+      f32x4 acc[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt) acc[rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* wrow = lds_w + (ct * 16 + r) * DP + q * (DP / 4);
+      const int swz = r & SWZ_MASK;
+#pragma unroll
+      for (int t = 0; t < CPQ; ++t) {
+        const float4 b = *reinterpret_cast<const float4*>(wrow + ((t ^ swz) << 2));
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][4 * t + e], bb[e], acc[rt], 0, 0, 0);
+      }
+      const int code = ch * CT + ct * 16 + r;
+      const float eev = ee[code];
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float d = __fmaf_rn(-2.0f, acc[rt][i], zzc[rt][i] + eev);  // fl(fl(zz+ee) - 2 dot)
+          const bool better = d < best[rt][i];                             // strict: lowest code wins ties
+          best[rt][i] = better ? d : best[rt][i];
+          bidx[rt][i] = better ? code : bidx[rt][i];
+        }
+    }
+  }
+  // ---- argmin across the 16 lanes (codes) that share this lane's rows; ties -> lowest index
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float d = best[rt][i];
+      int bi = bidx[rt][i];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float od = __shfl_xor(d, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool take = (od < d) || (od == d && oi < bi);
+        d = take ? od : d;
+        bi = take ? oi : bi;
+      }
+      if (r == 0) lds_idx[wave * ROWS_W + rt * 16 + 4 * q + i] = bi;
+    }
+  __syncthreads();
+
+  // ---- z_q gather, squared error, idx
+  float err = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t row = row0 + rt * 16 + r;
+    const bool live = row < B;
+    const int id = lds_idx[wave * ROWS_W + rt * 16 + r];
+    const float* wr = W + (size_t)id * D;
+    float* out = z_q + (live ? row : 0) * D;
+    if (live && q == 0) idx_out[row] = id;
+    float e = 0.f;
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {  // squared error on the lane's own k-slice (k = 4u+q)
+      float wv;
+      if constexpr (EXACT) {
+        wv = wr[4 * u + q];
+      } else {
+        const int k = 4 * u + q;
+        wv = wr[k < D ? k : D - 1];
+        wv = k < D ? wv : 0.f;
+      }
+      const float df = wv - a[rt][u];  // padded k: 0 - 0
+      e = __fmaf_rn(df, df, e);
+    }
+    if (live) {  // z_q row = codebook row: the row's 4 lanes copy alternating 16-byte pieces
+      if constexpr (EXACT) {
+#pragma unroll
+        for (int u4 = 0; u4 < NU / 4; ++u4) {
+          const int u = 4 * u4 + q;
+          *reinterpret_cast<float4*>(out + 4 * u) = *reinterpret_cast<const float4*>(wr + 4 * u);
+        }
+      } else {
+        for (int k = q; k < D; k += 4) out[k] = wr[k];
+      }
+    }
+    err += live ? e : 0.f;
+  }
+  const float tot = vq_block_sum(err, lds_red);
+  if (threadIdx.x == 0) err_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ bf16 main
+template <int DP, bool EXACT>
+__global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
+    const unsigned short* __restrict__ z, const float* __restrict__ W, const float* __restrict__ nhe,
+    const unsigned short* __restrict__ img, int64_t B, int n_e, int D, int n_ep,
+    unsigned short* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
+  constexpr int RT = 4;
+  constexpr int ROWS_W = RT * 16;
+  constexpr int BM = VQ_WAVES * ROWS_W;  // 256 rows per block
+  constexpr int CT = 64;
+  constexpr int KS = DP / 32;            // MFMA k-steps
+  constexpr int CPR = DP / 8;            // 16-byte chunks per codebook row
+  constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned short* lds_w = reinterpret_cast<unsigned short*>(smem);           // [CT][DP] bf16
+  int* lds_idx = reinterpret_cast<int*>(smem + CT * DP * 2);                 // [BM]
+  float* lds_red = reinterpret_cast<float*>(smem + CT * DP * 2 + BM * 4);    // [VQ_WAVES]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int64_t row0 = (int64_t)blockIdx.x * BM + wave * ROWS_W;
+
+  u16x8 a[RT][KS];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    int64_t row = row0 + rt * 16 + r;
+    row = row < B ? row : B - 1;
+    const unsigned short* zr = z + row * D;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 32 * s + 8 * q;
+      u16x8 v;
+      if constexpr (EXACT) {
+        v = *reinterpret_cast<const u16x8*>(zr + k0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const unsigned short t = zr[k0 + j < D ? k0 + j : D - 1];
+          v[j] = k0 + j < D ? t : (unsigned short)0;
+        }
+      }
+      a[rt][s] = v;
+    }
+  }
+
+  float best[RT][4];
+  int bidx[RT][4];
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { best[rt][i] = -INFINITY; bidx[rt][i] = 0; }
+
+  const int nch = n_ep / CT;
+  for (int ch = 0; ch < nch; ++ch) {
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(img + (size_t)ch * CT * DP);
+      float4* dst = reinterpret_cast<float4*>(lds_w);
+#pragma unroll
+      for (int i = 0; i < CT * DP / 8 / VQ_THREADS; ++i) dst[i * VQ_THREADS + threadIdx.x] = src[i * VQ_THREADS + threadIdx.x];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < CT / 16; ++ct) {
+      const int code = ch * CT + ct * 16 + r;
+      const float bias = nhe[code];  // -|w|^2/2 (or -inf for padding)
+      f32x4 acc[RT];
+      const unsigned short* wrow = lds_w + (ct * 16 + r) * DP;
+      const int swz = r & SWZ_MASK;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const u16x8 b = *reinterpret_cast<const u16x8*>(wrow + (((4 * s + q) ^ swz) << 3));
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+          const f32x4 cin = (s == 0) ? (f32x4){bias, bias, bias, bias} : acc[rt];
+          acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[rt][s]),
+                                                           __builtin_bit_cast(bf16x8_t, b), cin, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sc = acc[rt][i];
+          const bool better = sc > best[rt][i];  // strict: lowest code wins ties
+          best[rt][i] = better ? sc : best[rt][i];
+          bidx[rt][i] = better ? code : bidx[rt][i];
+        }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float sc = best[rt][i];
+      int bi = bidx[rt][i];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const float os = __shfl_xor(sc, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const bool take = (os > sc) || (os == sc && oi < bi);
+        sc = take ? os : sc;
+        bi = take ? oi : bi;
+      }
+      if (r == 0) lds_idx[wave * ROWS_W + rt * 16 + 4 * q + i] = bi;
+    }
+  __syncthreads();
+
+  float err = 0.f;
+#pragma unroll
+  for (int rt = 0; rt < RT; ++rt) {
+    const int64_t row = row0 + rt * 16 + r;
+    const bool live = row < B;
+    const int id = lds_idx[wave * ROWS_W + rt * 16 + r];
+    const float* wr = W + (size_t)id * D;
+    unsigned short* out = z_q + (live ? row : 0) * D;
+    if (live && q == 0) idx_out[row] = id;
+    float e = 0.f;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 32 * s + 8 * q;
+      float w[8];
+      if constexpr (EXACT) {
+        const float4 w0 = *reinterpret_cast<const float4*>(wr + k0);
+        const float4 w1 = *reinterpret_cast<const float4*>(wr + k0 + 4);
+        w[0] = w0.x; w[1] = w0.y; w[2] = w0.z; w[3] = w0.w;
+        w[4] = w1.x; w[5] = w1.y; w[6] = w1.z; w[7] = w1.w;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = wr[k0 + j < D ? k0 + j : D - 1];
+          w[j] = k0 + j < D ? t : 0.f;
+        }
+      }
+      u16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float df = w[j] - ceeg_bf16_to_f32(a[rt][s][j]);
+        e = __fmaf_rn(df, df, e);
+        o[j] = ceeg_f32_to_bf16(w[j]);
+      }
+      if constexpr (EXACT) {
+        if (live) *reinterpret_cast<u16x8*>(out + k0) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (live && k0 + j < D) out[k0 + j] = o[j];
+      }
+    }
+    err += live ? e : 0.f;
+  }
+  const float tot = vq_block_sum(err, lds_red);
+  if (threadIdx.x == 0) err_part[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------------------------------ histogram
+// slice g covers rows [g*rows_per, (g+1)*rows_per); counts in LDS (integer adds commute: deterministic)
+__global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int64_t rows_per,
+                               uint32_t* __restrict__ part /* [gridDim.x][n_e] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* h = reinterpret_cast<uint32_t*>(smem);
+  for (int c = threadIdx.x; c < n_e; c += blockDim.x) h[c] = 0;
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * rows_per;
+  const int64_t hi = lo + rows_per < B ? lo + rows_per : B;
+  for (int64_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
+    const int64_t k = idx[b];
+    if (k >= 0 && k < n_e) atomicAdd(&h[k], 1u);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_e; c += blockDim.x) part[(size_t)blockIdx.x * n_e + c] = h[c];
+}
+
+// one block: loss, perplexity, hist totals — every reduction in a fixed order
+__global__ void vq_finalize_kernel(const float* __restrict__ err_part, int nblk, const uint32_t* __restrict__ hpart,
+                                   int nslice, int n_e, int64_t B, int D, float beta, float* __restrict__ loss,
+                                   float* __restrict__ ppl, uint32_t* __restrict__ hist) {
+  __shared__ double red[256];
+  double e = 0.0;
+  for (int i = threadIdx.x; i < nblk; i += 256) e += (double)err_part[i];
+  double ent = 0.0;
+  for (int c = threadIdx.x; c < n_e; c += 256) {
+    uint32_t t = 0;
+    for (int g = 0; g < nslice; ++g) t += hpart[(size_t)g * n_e + c];
+    if (hist) hist[c] = t;
+    const float p = (float)t / (float)B;
+    ent += (double)(p * logf(p + 1e-10f));
+  }
+  red[threadIdx.x] = e;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const double sq = red[0];
+  __syncthreads();
+  red[threadIdx.x] = ent;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double m = sq / ((double)B * (double)D);
+    *loss = (float)(m + (double)beta * m);
+    *ppl = (float)exp(-red[0]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+template <bool BF16>
+__device__ __forceinline__ float vq_ld(const void* p, size_t i) {
+  if (BF16) return ceeg_bf16_to_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+  return reinterpret_cast<const float*>(p)[i];
+}
+
+// dz = g + s*(2/M)*(z - W[idx])
+template <bool BF16>
+__global__ void vq_dz_kernel(const void* __restrict__ z, const float* __restrict__ W, const int64_t* __restrict__ idx,
+                             const void* __restrict__ g, const float* __restrict__ s_dev, int64_t B, int D,
+                             void* __restrict__ dz) {
+  const float coef = s_dev[0] * (2.0f / ((float)B * (float)D));
+  const int64_t total = B * D;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / D;
+    const int k = (int)(i - b * D);
+    const float zv = vq_ld<BF16>(z, i);
+    const float w = W[(size_t)idx[b] * D + k];
+    float v = coef * (zv - w);
+    if (g) v += vq_ld<BF16>(g, i);
+    if (BF16) reinterpret_cast<unsigned short*>(dz)[i] = ceeg_f32_to_bf16(v);
+    else reinterpret_cast<float*>(dz)[i] = v;
+  }
+}
+
+// scan of the per-slice histograms: off[g][c] = (rows with smaller code) + (rows with code c in slices < g);
+// also the per-code chunk table for the segmented sum.  One block.
+__global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, int n_e, uint32_t* __restrict__ off,
+                               uint32_t* __restrict__ code_base /* [n_e+1] */, uint32_t* __restrict__ chunk_base /* [n_e+1] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
+  for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
+    uint32_t t = 0;
+    for (int g = 0; g < nslice; ++g) t += hpart[(size_t)g * n_e + c];
+    tot[c] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0, crun = 0;
+    for (int c = 0; c < n_e; ++c) {
+      code_base[c] = run;
+      chunk_base[c] = crun;
+      run += tot[c];
+      crun += (tot[c] + VQ_SEG - 1) / VQ_SEG;
+    }
+    code_base[n_e] = run;
+    chunk_base[n_e] = crun;
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
+    uint32_t run = code_base[c];
+    for (int g = 0; g < nslice; ++g) {
+      off[(size_t)g * n_e + c] = run;
+      run += hpart[(size_t)g * n_e + c];
+    }
+  }
+}
+
+// stable scatter: one wave per slice walks its rows in order, 64 at a time; equal codes inside a batch are
+// ranked by lane order -> sorted[] lists the rows of each code in ascending row order (deterministic).
+__global__ __launch_bounds__(64) void vq_scatter_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int64_t rows_per,
+                                                        const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [n_e]
+  const int lane = threadIdx.x;
+  for (int c = lane; c < n_e; c += 64) cur[c] = off[(size_t)blockIdx.x * n_e + c];
+  __syncthreads();
+  const int64_t lo = (int64_t)blockIdx.x * rows_per;
+  const int64_t hi = lo + rows_per < B ? lo + rows_per : B;
+  for (int64_t b0 = lo; b0 < hi; b0 += 64) {
+    const int64_t b = b0 + lane;
+    const bool valid = b < hi;
+    int k = valid ? (int)idx[b] : -1;
+    if (k < 0 || k >= n_e) k = -1;
+    unsigned long long rem = __ballot(k >= 0);
+    while (rem) {
+      const int leader = __ffsll((long long)rem) - 1;
+      const int k0 = __shfl(k, leader, 64);
+      const unsigned long long m = __ballot(k == k0);
+      const uint32_t base = cur[k0];
+      if (k == k0) sorted[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
+      __syncthreads();  // single-wave block: orders the LDS read above before the update below
+      if (lane == leader) cur[k0] = base + (uint32_t)__popcll(m);
+      __syncthreads();
+      rem &= ~m;
+    }
+  }
+}
+
+// segmented sum: one wave per (code, chunk of <= VQ_SEG sorted rows); rows are added in list order.
+template <bool BF16>
+__global__ __launch_bounds__(256) void vq_segsum_kernel(const void* __restrict__ z, const uint32_t* __restrict__ sorted,
+                                                        const uint32_t* __restrict__ code_base, const uint32_t* __restrict__ chunk_base,
+                                                        int n_e, int D, float* __restrict__ partial /* [nchunks][D] */) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= chunk_base[n_e]) return;
+  int lo = 0, hi = n_e;  // last code c with chunk_base[c] <= w
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (chunk_base[mid] <= w) lo = mid; else hi = mid;
+  }
+  const int c = lo;
+  const uint32_t p0 = code_base[c] + (w - chunk_base[c]) * VQ_SEG;
+  const uint32_t p1 = p0 + VQ_SEG < code_base[c + 1] ? p0 + VQ_SEG : code_base[c + 1];
+  for (int k = lane; k < D; k += 64) {
+    float acc = 0.f;
+    for (uint32_t p = p0; p < p1; ++p) acc += vq_ld<BF16>(z, (size_t)sorted[p] * D + k);
+    partial[(size_t)w * D + k] = acc;
+  }
+}
+
+// dW[c] = s*beta*(2/M) * (count_c * W[c] - sum of the code's chunk partials, in chunk order)
+__global__ void vq_dw_kernel(const float* __restrict__ W, const float* __restrict__ partial, const uint32_t* __restrict__ code_base,
+                             const uint32_t* __restrict__ chunk_base, const float* __restrict__ s_dev, int64_t B, int n_e, int D,
+                             float beta, float* __restrict__ dW) {
+  const int c = blockIdx.x;
+  const float coef = s_dev[0] * beta * (2.0f / ((float)B * (float)D));
+  const float cnt = (float)(code_base[c + 1] - code_base[c]);
+  for (int k = threadIdx.x; k < D; k += blockDim.x) {
+    float sum = 0.f;
+    for (uint32_t w = chunk_base[c]; w < chunk_base[c + 1]; ++w) sum += partial[(size_t)w * D + k];
+    dW[(size_t)c * D + k] = coef * (cnt * W[(size_t)c * D + k] - sum);
+  }
+}
+
+int vq_dp(int D, int dtype) {
+  const int lo = dtype == CEEG_BF16 ? 32 : 16;
+  int dp = lo;
+  while (dp < D) dp <<= 1;
+  return dp;
+}
+int vq_ct(int dtype) { return dtype == CEEG_BF16 ? 64 : 32; }
+int vq_bm(int dtype) { return dtype == CEEG_BF16 ? 256 : 128; }
+int64_t vq_nslice(int64_t B) { return (B + VQ_HIST_ROWS - 1) / VQ_HIST_ROWS; }
+
+struct VqFwdWs {
+  float* ee;
+  void* img;
+  float* err_part;
+  uint32_t* hpart;
+};
+size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_bytes, VqFwdWs* out) {
+  const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
+  const int n_ep = (n_e + CT - 1) / CT * CT;
+  const int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
+  CeegWs a(ws, ws_bytes);
+  size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP, dtype == CEEG_BF16 ? 2 : 4) +
+                ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)vq_nslice(B) * n_e, 4);
+  if (out) {
+    out->ee = a.take<float>(n_ep);
+    out->img = a.take<char>((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4));
+    out->err_part = a.take<float>(nblk);
+    out->hpart = a.take<uint32_t>((size_t)vq_nslice(B) * n_e);
+    if (!a.ok) return 0;
+  }
+  return need;
+}
+
+template <int DP>
+void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, float* z_q,
+                int64_t* idx, int64_t nblk, hipStream_t st) {
+  const size_t lds = 32 * DP * 4 + 128 * 4 + VQ_WAVES * 4;
+  if (D == DP)
+    hipLaunchKernelGGL((vq_main_f32<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
+                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
+  else
+    hipLaunchKernelGGL((vq_main_f32<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
+                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
+}
+template <int DP>
+void launch_bf16(const void* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, void* z_q,
+                 int64_t* idx, int64_t nblk, hipStream_t st) {
+  const size_t lds = 64 * DP * 2 + 256 * 4 + VQ_WAVES * 4;
+  if (D == DP)
+    hipLaunchKernelGGL((vq_main_bf16<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st,
+                       reinterpret_cast<const unsigned short*>(z), W, w.ee, reinterpret_cast<const unsigned short*>(w.img), B,
+                       n_e, D, n_ep, reinterpret_cast<unsigned short*>(z_q), idx, w.err_part);
+  else
+    hipLaunchKernelGGL((vq_main_bf16<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st,
+                       reinterpret_cast<const unsigned short*>(z), W, w.ee, reinterpret_cast<const unsigned short*>(w.img), B,
+                       n_e, D, n_ep, reinterpret_cast<unsigned short*>(z_q), idx, w.err_part);
+}
+
+}  // namespace
+
+extern "C" size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype) {
+  if (B <= 0 || n_e <= 0 || D <= 0 || D > 256) return 0;
+  return vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr);
+}
+
+extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
+                               void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
+                               void* ws, size_t ws_bytes, void* stream) {
+  if (!z || !W || !z_q || !idx || !loss || !perplexity || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
+  if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
+  if (D > 256 || n_e > 16384 || B > ((int64_t)1 << 31) * 128) return CEEG_EUNSUPPORTED;
+  if (!ceeg_aligned(z, 16) || !ceeg_aligned(z_q, 16) || !ceeg_aligned(W, 16)) return CEEG_EINVAL;
+  VqFwdWs w;
+  if (ws_bytes < vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
+  if (!ws || !ceeg_aligned(ws, 256) || vq_fwd_layout(B, n_e, D, dtype, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
+  const int n_ep = (n_e + CT - 1) / CT * CT;
+  const int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
+
+  const int prep_blocks = (int)(((int64_t)n_ep * DP + 255) / 256 < 1024 ? ((int64_t)n_ep * DP + 255) / 256 : 1024);
+  if (dtype == CEEG_BF16)
+    hipLaunchKernelGGL(vq_prep_kernel<true>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, w.ee, w.img);
+  else
+    hipLaunchKernelGGL(vq_prep_kernel<false>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, w.ee, w.img);
+  CEEG_CHECK_LAUNCH();
+
+  if (dtype == CEEG_F32) {
+    const float* zf = static_cast<const float*>(z);
+    float* zq = static_cast<float*>(z_q);
+    switch (DP) {
+      case 16: launch_f32<16>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      case 32: launch_f32<32>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      case 64: launch_f32<64>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      case 128: launch_f32<128>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      case 256: launch_f32<256>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      default: return CEEG_EUNSUPPORTED;
+    }
+  } else {
+    switch (DP) {
+      case 32: launch_bf16<32>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 64: launch_bf16<64>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 128: launch_bf16<128>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 256: launch_bf16<256>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      default: return CEEG_EUNSUPPORTED;
+    }
+  }
+  CEEG_CHECK_LAUNCH();
+
+  const int nslice = (int)vq_nslice(B);
+  hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.hpart);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, w.err_part, (int)nblk, w.hpart, nslice, n_e, B, D, beta,
+                     loss, perplexity, hist);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- backward API
+namespace {
+struct VqBwdWs {
+  uint32_t *hpart, *off, *code_base, *chunk_base, *sorted;
+  float* partial;
+};
+size_t vq_bwd_layout(int64_t B, int n_e, int D, void* ws, size_t ws_bytes, VqBwdWs* out) {
+  const int64_t nslice = vq_nslice(B);
+  const int64_t nchunk_max = B / VQ_SEG + n_e + 1;
+  size_t need = 2 * ceeg_ws_part((size_t)nslice * n_e, 4) + 2 * ceeg_ws_part(n_e + 1, 4) + ceeg_ws_part(B, 4) +
+                ceeg_ws_part((size_t)nchunk_max * D, 4);
+  if (out) {
+    CeegWs a(ws, ws_bytes);
+    out->hpart = a.take<uint32_t>((size_t)nslice * n_e);
+    out->off = a.take<uint32_t>((size_t)nslice * n_e);
+    out->code_base = a.take<uint32_t>(n_e + 1);
+    out->chunk_base = a.take<uint32_t>(n_e + 1);
+    out->sorted = a.take<uint32_t>(B);
+    out->partial = a.take<float>((size_t)nchunk_max * D);
+    if (!a.ok) return 0;
+  }
+  return need;
+}
+}  // namespace
+
+extern "C" size_t ceeg_vq_backward_ws_bytes(int64_t B, int n_e, int D, int dtype) {
+  (void)dtype;
+  if (B <= 0 || n_e <= 0 || D <= 0) return 0;
+  return vq_bwd_layout(B, n_e, D, nullptr, 0, nullptr);
+}
+
+extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* idx, const void* g, const float* s_dev,
+                                int64_t B, int n_e, int D, int dtype, float beta, void* dz, float* dW,
+                                void* ws, size_t ws_bytes, void* stream) {
+  if (!z || !W || !idx || !s_dev || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
+  if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
+  if (n_e > 16384 || B >= ((int64_t)1 << 32)) return CEEG_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dz) {
+    const int64_t total = B * D;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dtype == CEEG_BF16)
+      hipLaunchKernelGGL(vq_dz_kernel<true>, dim3(blocks), dim3(256), 0, st, z, W, idx, g, s_dev, B, D, dz);
+    else
+      hipLaunchKernelGGL(vq_dz_kernel<false>, dim3(blocks), dim3(256), 0, st, z, W, idx, g, s_dev, B, D, dz);
+    CEEG_CHECK_LAUNCH();
+  }
+  if (dW) {
+    VqBwdWs w;
+    if (ws_bytes < vq_bwd_layout(B, n_e, D, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
+    if (!ws || !ceeg_aligned(ws, 256) || vq_bwd_layout(B, n_e, D, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+    const int nslice = (int)vq_nslice(B);
+    hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.hpart);
+    CEEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(512), (size_t)n_e * 4, st, w.hpart, nslice, n_e, w.off, w.code_base, w.chunk_base);
+    CEEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(nslice), dim3(64), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.off, w.sorted);
+    CEEG_CHECK_LAUNCH();
+    const int64_t nchunk_max = B / VQ_SEG + n_e + 1;
+    const unsigned sblocks = (unsigned)((nchunk_max + 3) / 4);
+    if (dtype == CEEG_BF16)
+      hipLaunchKernelGGL(vq_segsum_kernel<true>, dim3(sblocks), dim3(256), 0, st, z, w.sorted, w.code_base, w.chunk_base, n_e, D, w.partial);
+    else
+      hipLaunchKernelGGL(vq_segsum_kernel<false>, dim3(sblocks), dim3(256), 0, st, z, w.sorted, w.code_base, w.chunk_base, n_e, D, w.partial);
+    CEEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(vq_dw_kernel, dim3(n_e), dim3(256), 0, st, W, w.partial, w.code_base, w.chunk_base, s_dev, B, n_e, D, beta, dW);
+    CEEG_CHECK_LAUNCH();
+  }
+  return CEEG_OK;
+}

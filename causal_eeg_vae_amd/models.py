@@ -1,0 +1,440 @@
+"""Host-side model API of the VGAE + VQ training step on MI355X.
+
+Mirrors the surface the north star names: PyG-style `GCNConv`, `VGAE` with
+`encode / reparametrize / kl_loss / recon_loss`, `InnerProductDecoder`, `negative_sampling`, and the
+reference's `VectorQuantizer` (scripts/quantizer.py) placed after the encoder exactly where
+`BaseCVAE.forward` puts it (scripts/models.py:30-34).  torch_geometric is NOT a dependency: the
+semantics are restated from SURVEY.md §8(a) rows A3-A6 ("parity unpinned": the reference neither
+vendors nor pins PyG, environment.yml:13).
+
+Everything numeric goes through libceeg.so (include/ceeg.h); PyTorch supplies device memory, the
+stream, autograd bookkeeping and the dense feature transforms x @ W^T (hipBLASLt via torch.mm —
+"plain library GEMMs").  There is no CPU fallback.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .quantizer import VectorQuantizer
+
+MAX_LOGSTD = 10  # /root/reference/scripts/run.py:13 (== upstream PyG autoencoder.MAX_LOGSTD)
+EPS = 1e-15
+
+
+# ==================================================================================================
+# Graph structure: canonical CSR (by dst, then src, then edge id) + its transpose, built once per graph
+# ==================================================================================================
+class CsrPair:
+    """A CSR grouped by destination and its transpose (grouped by source) with the value permutation."""
+
+    def __init__(self, edge_index, num_nodes, self_loops):
+        _lib.require_cuda(edge_index)
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        L = _lib.lib()
+        dev = edge_index.device
+        ei = edge_index.to(torch.int64).contiguous()
+        E, N = ei.shape[1], int(num_nodes)
+        cap = E + (N if self_loops else 0)
+        self.num_nodes, self.self_loops = N, bool(self_loops)
+        self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        perm = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+        nnz_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
+        _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
+                                    col.data_ptr(), perm.data_ptr(), nnz_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    _lib.stream()), "ceeg_csr_build")
+        self.nnz = int(nnz_dev.item())  # one host sync at graph-construction time (never inside a step)
+        self.col, self.perm = col[: self.nnz], perm[: self.nnz]
+        self.t_rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        self.t_col = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)[: self.nnz]
+        self.t_perm = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)[: self.nnz]
+        ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(self.nnz, N), dev)
+        _lib.check(L.ceeg_csr_transpose(self.rowptr.data_ptr(), self.col.data_ptr(), self.nnz, N, self.t_rowptr.data_ptr(),
+                                        self.t_col.data_ptr(), self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                        _lib.stream()), "ceeg_csr_transpose")
+
+    @property
+    def device(self):
+        return self.rowptr.device
+
+
+class EventGraph:
+    """An event graph (edges old_id -> new_id, /root/reference/scripts/dataset.py:147-153) prepared for the
+    GCN encoder (`gcn`: A + I with symmetric normalisation) and the decoder (`dec`: the raw edges).
+    Build it once per graph / minibatch; every step reuses the structures."""
+
+    def __init__(self, edge_index, num_nodes, edge_weight=None):
+        self.edge_index = edge_index
+        self.num_nodes = int(num_nodes)
+        self.num_edges = int(edge_index.shape[1])
+        self.gcn = CsrPair(edge_index, num_nodes, self_loops=True)
+        L = _lib.lib()
+        dev = edge_index.device
+        ew = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
+        self.dinv = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
+        self.gcn_val = torch.empty(max(self.gcn.nnz, 1), dtype=torch.float32, device=dev)[: self.gcn.nnz]
+        _lib.check(L.ceeg_gcn_norm(self.gcn.rowptr.data_ptr(), self.gcn.col.data_ptr(), self.gcn.perm.data_ptr(), _lib.ptr(ew),
+                                   self.gcn.nnz, self.num_nodes, self.dinv.data_ptr(), self.gcn_val.data_ptr(), _lib.stream()),
+                   "ceeg_gcn_norm")
+        self._dec = None
+
+    @property
+    def dec(self):
+        if self._dec is None:
+            self._dec = CsrPair(self.edge_index, self.num_nodes, self_loops=False)
+        return self._dec
+
+
+def _as_graph(g, num_nodes):
+    if isinstance(g, EventGraph):
+        return g
+    return EventGraph(g, num_nodes)
+
+
+def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False):
+    L = _lib.lib()
+    nnz = col.shape[0]
+    F = x.shape[1]
+    if out is None:
+        out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
+    ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
+    _lib.check(L.ceeg_spmm_csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
+                               n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
+                               ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr")
+    return out
+
+
+class _GcnAggregate(torch.autograd.Function):
+    """out = act(A_hat @ h + b); backward dh = A_hat^T @ g through the transposed CSR (values via t_perm)."""
+
+    @staticmethod
+    def forward(ctx, h, bias, graph, relu):
+        _lib.require_cuda(h)
+        h = h.contiguous()
+        g = graph.gcn
+        out = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, bias=bias, relu=relu)
+        ctx.graph, ctx.relu, ctx.has_bias = graph, bool(relu), bias is not None
+        if relu:
+            ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        graph, g = ctx.graph, ctx.graph.gcn
+        grad = grad.contiguous()
+        if ctx.relu:
+            (out,) = ctx.saved_tensors
+            grad = grad * (out > 0)
+        dbias = grad.sum(dim=0) if ctx.has_bias else None
+        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_val, g.t_perm, grad, graph.num_nodes)
+        return dh, dbias, None, None
+
+
+def glorot_(w):
+    a = math.sqrt(6.0 / (w.shape[0] + w.shape[1]))
+    with torch.no_grad():
+        w.uniform_(-a, a)
+
+
+class _Lin(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(o, i))
+        glorot_(self.weight)
+
+
+class GCNConv(nn.Module):
+    """PyG-style GCNConv(in_channels, out_channels): out = D^-1/2 (A+I) D^-1/2 (x W^T) + b.
+    Linear first (no bias inside, glorot), then the deterministic CSR SpMM, then + b (zeros init).
+    State-dict keys `lin.weight`, `bias` as upstream."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.lin = _Lin(in_channels, out_channels)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, graph, edge_weight=None, relu=False):
+        if not isinstance(graph, EventGraph):
+            graph = EventGraph(graph, x.shape[0], edge_weight)
+        return _GcnAggregate.apply(x @ self.lin.weight.t(), self.bias, graph, relu)
+
+
+# ==================================================================================================
+# Reparametrisation + KL (fused), decoder
+# ==================================================================================================
+class _ReparamKL(torch.autograd.Function):
+    """(z, kl) = fused reparametrise + KL.  `logstd is None` means `mu` is the fused [N, 2D] encoder output
+    (mu | logstd), read in place through row strides; its gradient then comes back as ONE [N, 2D] tensor."""
+
+    @staticmethod
+    def forward(ctx, mu, logstd, eps, seed, training, log_var):
+        _lib.require_cuda(mu, logstd)
+        L = _lib.lib()
+        fused = logstd is None
+        if fused:
+            ml = mu.contiguous()
+            N, D = ml.shape[0], ml.shape[1] // 2
+            mu_v, ls_v = ml[:, :D], ml[:, D:]
+        else:
+            N, D = mu.shape
+            mu_v = mu if mu.stride(1) == 1 else mu.contiguous()
+            ls_v = logstd if logstd.stride(1) == 1 else logstd.contiguous()
+        epsc = None if eps is None else eps.contiguous()
+        z = torch.empty(N, D, dtype=torch.float32, device=mu.device)
+        kl = torch.empty((), dtype=torch.float32, device=mu.device)
+        ws = _lib.workspace(L.ceeg_reparam_kl_ws_bytes(N, D), mu.device)
+        _lib.check(L.ceeg_reparam_kl_fwd(mu_v.data_ptr(), mu_v.stride(0), ls_v.data_ptr(), ls_v.stride(0), _lib.ptr(epsc), int(seed),
+                                         N, D, float(MAX_LOGSTD), int(log_var), int(training), z.data_ptr(), kl.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_kl_fwd")
+        ctx.save_for_backward(mu_v, ls_v, epsc)
+        ctx.seed, ctx.training, ctx.log_var, ctx.fused = int(seed), int(training), int(log_var), fused
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, gz, gkl):
+        mu, logstd, epsc = ctx.saved_tensors
+        L = _lib.lib()
+        N, D = mu.shape
+        dml = torch.empty(N, 2 * D, dtype=torch.float32, device=mu.device)
+        gzc = None if gz is None else gz.contiguous()
+        gk = None if gkl is None else gkl.reshape(1).contiguous()
+        _lib.check(L.ceeg_reparam_kl_bwd(mu.data_ptr(), mu.stride(0), logstd.data_ptr(), logstd.stride(0), _lib.ptr(epsc), ctx.seed,
+                                         _lib.ptr(gzc), _lib.ptr(gk), N, D, float(MAX_LOGSTD), ctx.log_var, ctx.training,
+                                         dml.data_ptr(), 2 * D, dml[:, D:].data_ptr(), 2 * D, _lib.stream()), "ceeg_reparam_kl_bwd")
+        if ctx.fused:
+            return dml, None, None, None, None, None
+        return dml[:, :D], dml[:, D:], None, None, None, None
+
+
+def _edge_lists_i32(edge_index):
+    ei = edge_index.to(torch.int32)
+    return ei[0].contiguous(), ei[1].contiguous()
+
+
+class _EdgeBCE(torch.autograd.Function):
+    """sum_e term_e over an arbitrary edge list; backward = two SpMMs over the list's CSR and transpose."""
+
+    @staticmethod
+    def forward(ctx, z, edge_index, negative, pair):
+        _lib.require_cuda(z, edge_index)
+        L = _lib.lib()
+        z = z.contiguous()
+        N, D = z.shape
+        i, j = _edge_lists_i32(edge_index)
+        E = i.shape[0]
+        coef = torch.empty(max(E, 1), dtype=torch.float32, device=z.device)[:E]
+        out = torch.zeros((), dtype=torch.float32, device=z.device)
+        ws = _lib.workspace(L.ceeg_edge_bce_ws_bytes(E, D), z.device)
+        _lib.check(L.ceeg_edge_bce_fwd(z.data_ptr(), z.stride(0), i.data_ptr(), j.data_ptr(), E, D, int(negative), coef.data_ptr(),
+                                       None, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
+        ctx.save_for_backward(z, coef)
+        ctx.edge_index, ctx.pair = edge_index, pair
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        z, coef = ctx.saved_tensors
+        N = z.shape[0]
+        pair = ctx.pair if ctx.pair is not None else CsrPair(ctx.edge_index, N, self_loops=False)
+        # CSR rows = edge_index[1] (j), cols = edge_index[0] (i); perm maps CSR position -> edge id
+        cv = coef[pair.perm.long()] * g
+        dz = _spmm(pair.rowptr, pair.col, cv, None, z, N)
+        _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True)
+        return dz, None, None, None
+
+
+class InnerProductDecoder(nn.Module):
+    """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge."""
+
+    def forward(self, z, edge_index, sigmoid=True):
+        _lib.require_cuda(z, edge_index)
+        L = _lib.lib()
+        zc = z.contiguous()
+        i, j = _edge_lists_i32(edge_index)
+        E, D = i.shape[0], zc.shape[1]
+        prob = torch.empty(max(E, 1), dtype=torch.float32, device=z.device)[:E]
+        out = torch.zeros((), dtype=torch.float32, device=z.device)
+        ws = _lib.workspace(L.ceeg_edge_bce_ws_bytes(E, D), z.device)
+        _lib.check(L.ceeg_edge_bce_fwd(zc.data_ptr(), zc.stride(0), i.data_ptr(), j.data_ptr(), E, D, 0, None, prob.data_ptr(),
+                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
+        return prob if sigmoid else torch.logit(prob)
+
+    def forward_all(self, z, sigmoid=True):
+        adj = z @ z.t()  # dense N x N: small graphs only (out of scope at N = 1M)
+        return torch.sigmoid(adj) if sigmoid else adj
+
+
+def negative_sampling(edge_index, num_nodes, num_neg_samples=None, seed=0, graph=None):
+    """Uniform negative sampler (PyG negative_sampling surface).  Deterministic under `seed`
+    (Philox4x32-10, restated in oracle/ceeg_oracle.c); samples that collide 16 times are dropped."""
+    _lib.require_cuda(edge_index)
+    L = _lib.lib()
+    pair = graph.dec if isinstance(graph, EventGraph) else CsrPair(edge_index, num_nodes, self_loops=False)
+    num = int(edge_index.shape[1] if num_neg_samples is None else num_neg_samples)
+    s = torch.empty(max(num, 1), dtype=torch.int32, device=edge_index.device)[:num]
+    d = torch.empty(max(num, 1), dtype=torch.int32, device=edge_index.device)[:num]
+    _lib.check(L.ceeg_neg_sample_uniform(pair.rowptr.data_ptr(), pair.col.data_ptr(), num_nodes, num, int(seed), s.data_ptr(),
+                                         d.data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform")
+    out = torch.stack([s, d]).to(torch.int64)
+    return out[:, out[0] >= 0]
+
+
+def sigma_params(num_nodes, seed, step):
+    """(a, b, a^-1) of the per-step node permutation sigma(x) = (a x + b) mod N used by the fused decoder's
+    permutation-structured negatives; splitmix64 of (seed, step), a bumped until gcd(a, N) == 1."""
+    def mix(x):
+        x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+        x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+        x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+        return x ^ (x >> 31)
+    N = int(num_nodes)
+    if N < 2:
+        return 1, 0, 1
+    h = mix(mix(int(seed)) ^ (int(step) * 0xD1342543DE82EF95 & (2**64 - 1)))
+    a = 1 + h % (N - 1)
+    while math.gcd(a, N) != 1:
+        a = 1 + a % (N - 1)
+    b = mix(h) % N
+    return a, b, pow(a, -1, N)
+
+
+class _FusedDecoder(torch.autograd.Function):
+    """recon_loss with permutation-structured negatives: one gather pass for both terms (ceeg_decoder_fused_*)."""
+
+    @staticmethod
+    def forward(ctx, z, graph, a, b, ainv):
+        _lib.require_cuda(z)
+        L = _lib.lib()
+        z = z.contiguous()
+        N, D = z.shape
+        p = graph.dec
+        cp = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
+        cn = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
+        sums = torch.empty(3, dtype=torch.float32, device=z.device)
+        ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
+        _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b,
+                                            cp.data_ptr(), cn.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _lib.stream()), "ceeg_decoder_fused_fwd")
+        inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
+        ctx.save_for_backward(z, cp, cn, inv)
+        ctx.graph, ctx.sig = graph, (a, b, ainv)
+        ctx.mark_non_differentiable(sums)
+        return sums[0] * inv[0] + sums[1] * inv[1], sums
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        z, cp, cn, inv = ctx.saved_tensors
+        L = _lib.lib()
+        N, D = z.shape
+        p = ctx.graph.dec
+        a, b, ainv = ctx.sig
+        gscale = (inv * g).contiguous()
+        dz = torch.empty_like(z)
+        ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
+        _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
+                                            p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, cp.data_ptr(),
+                                            cn.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(),
+                                            _lib.stream()), "ceeg_decoder_fused_bwd")
+        return dz, None, None, None, None
+
+
+# ==================================================================================================
+# VGAE (PyG surface) and the VGAE + VQ model of the north-star step
+# ==================================================================================================
+class VariationalGCNEncoder(nn.Module):
+    """2-layer variational GCN encoder (PyG example convention): conv1 F_in -> 2*latent (ReLU),
+    conv_mu / conv_logstd 2*latent -> latent.  The two heads run as ONE SpMM over h @ [W_mu | W_sigma]^T."""
+
+    def __init__(self, in_channels, latent):
+        super().__init__()
+        self.conv1 = GCNConv(in_channels, 2 * latent)
+        self.conv_mu = GCNConv(2 * latent, latent)
+        self.conv_logstd = GCNConv(2 * latent, latent)
+        self.latent = latent
+
+    def forward_fused(self, x, graph):
+        h = self.conv1(x, graph, relu=True)
+        wcat = torch.cat([self.conv_mu.lin.weight, self.conv_logstd.lin.weight], dim=0)
+        bcat = torch.cat([self.conv_mu.bias, self.conv_logstd.bias], dim=0)
+        return _GcnAggregate.apply(h @ wcat.t(), bcat, graph, False)  # [N, 2*latent] = mu | logstd
+
+    def forward(self, x, graph):
+        graph = _as_graph(graph, x.shape[0])
+        ml = self.forward_fused(x, graph)
+        return ml[:, : self.latent], ml[:, self.latent:]
+
+
+class VGAE(nn.Module):
+    """PyG VGAE surface: encode / reparametrize / kl_loss / recon_loss / decoder."""
+
+    def __init__(self, encoder, decoder=None):
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = InnerProductDecoder() if decoder is None else decoder
+        self.seed, self._step = 0, 0
+        self.__mu__ = self.__logstd__ = self.__kl__ = None
+
+    def reparametrize(self, mu, logstd, eps=None):
+        """z = mu + eps * exp(min(logstd, MAX_LOGSTD)) in training, mu in eval; eps=None draws Philox noise
+        keyed by (self.seed, step).  Also caches the fused KL for kl_loss()."""
+        seed = (self.seed * 0x9E3779B1 + self._step) & (2**63 - 1)
+        z, kl = _ReparamKL.apply(mu, logstd, eps, seed, self.training, False)
+        self.__kl__ = kl
+        return z
+
+    def encode(self, *args, eps=None, **kwargs):
+        self.__mu__, self.__logstd__ = self.encoder(*args, **kwargs)
+        z = self.reparametrize(self.__mu__, self.__logstd__, eps=eps)
+        self._step += 1
+        return z
+
+    def kl_loss(self, mu=None, logstd=None):
+        if mu is None and logstd is None and self.__kl__ is not None:
+            return self.__kl__
+        mu = self.__mu__ if mu is None else mu
+        logstd = self.__logstd__ if logstd is None else logstd
+        _, kl = _ReparamKL.apply(mu, logstd, None, 0, False, False)
+        return kl
+
+    def recon_loss(self, z, pos_edge_index, neg_edge_index=None, graph=None):
+        N = z.shape[0]
+        pos_pair = graph.dec if isinstance(graph, EventGraph) else None
+        E = pos_edge_index.shape[1]
+        pos = _EdgeBCE.apply(z, pos_edge_index, False, pos_pair) / max(E, 1)
+        if neg_edge_index is None:
+            neg_edge_index = negative_sampling(pos_edge_index, N, seed=self.seed + self._step, graph=graph)
+        neg = _EdgeBCE.apply(z, neg_edge_index, True, None) / max(neg_edge_index.shape[1], 1)
+        return pos + neg
+
+
+class VGAEVQ(nn.Module):
+    """GCN-VGAE + VQ bottleneck: the north-star training step.
+
+        mu, logstd = encoder(x, graph);  z = reparametrize;  kl = kl_loss
+        vq_loss, z_q, perplexity, _, idx = vector_quantization(z)      (scripts/models.py:32)
+        rec = recon_loss(z_q) over the graph's edges and 1:1 permutation-structured negatives
+        loss = rec + kl / N + vq_loss                                   (loss sum as scripts/run.py:95)
+    """
+
+    def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0):
+        super().__init__()
+        self.encoder = VariationalGCNEncoder(in_channels, latent)
+        self.vector_quantization = VectorQuantizer(num_latent_embeddings, latent, beta, return_one_hot=False)
+        self.latent, self.seed = latent, int(seed)
+
+    def forward(self, x, graph, step=0, eps=None, sigma=None):
+        N = x.shape[0]
+        ml = self.encoder.forward_fused(x, graph)
+        D = self.latent
+        seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
+        z, kl = _ReparamKL.apply(ml, None, eps, seed, self.training, False)
+        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
+        rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv)
+        loss = rec + kl / N + vq_loss
+        return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)

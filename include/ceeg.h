@@ -1,0 +1,194 @@
+/*
+ * ceeg.h — C-ABI of libceeg.so: the MI355X (gfx950) hot path of the VGAE + VQ training step.
+ *
+ * The reference (bendavidsteel/causal-eeg-vae) exposes NO FFI/operator interface: its boundary is
+ * the Python nn.Module call convention.  Each entry point below names the
+ * reference (or upstream-PyG) call it stands behind.  Citations are relative to /root/reference.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only: raw DEVICE pointers + explicit sizes; contiguous row-major tensors;
+ *   - the CALLER owns every buffer including `ws` (workspace).  Nothing here calls hipMalloc/hipFree.
+ *     Workspace sizes come from the matching ceeg_*_ws_bytes() query (pure host arithmetic);
+ *   - stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the null stream);
+ *     no host synchronisation inside, re-entrant, no global mutable state;
+ *   - returns CEEG_OK (0) or a negative CEEG_E* code; ceeg_strerror() gives the text.  Host-side
+ *     argument/shape validation happens BEFORE any launch, so a bad call never faults the GPU;
+ *   - results are bitwise reproducible run to run: no float atomics anywhere.
+ */
+#ifndef CEEG_H
+#define CEEG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CEEG_VERSION 100 /* 0.1.0 */
+
+enum {
+  CEEG_OK = 0,
+  CEEG_EINVAL = -1,       /* null pointer / negative size / misaligned pointer */
+  CEEG_EUNSUPPORTED = -2, /* shape or dtype outside what the kernels implement */
+  CEEG_EWORKSPACE = -3,   /* ws_bytes smaller than the ws_bytes() query */
+  CEEG_ELAUNCH = -4,      /* hipGetLastError() != hipSuccess after a launch */
+  CEEG_ENODEVICE = -5     /* no HIP device / wrong architecture */
+};
+
+/* element types of z / z_q / features */
+enum { CEEG_F32 = 0, CEEG_BF16 = 1 };
+
+int ceeg_version(void);
+const char* ceeg_strerror(int code);
+/* Reads hipGetDeviceProperties of the current device: returns CEEG_OK on gfx950, else CEEG_ENODEVICE. */
+int ceeg_check_device(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A2  VectorQuantizer.forward — scripts/quantizer.py:25-67 (callers scripts/models.py:32,50)
+ *
+ *   d[b,c] = fl(fl(zz[b] + ee[c]) - 2*dot[b,c])            (quantizer.py:43-45; op order kept)
+ *   idx[b] = argmin_c d[b,c], LOWEST index on exact ties   (quantizer.py:48)
+ *   z_q[b] = W[idx[b]]                                     (quantizer.py:49-54; one-hot never built)
+ *   sqerr  = sum_b sum_k (z_q[b,k]-z[b,k])^2               (quantizer.py:57-58, both terms share it)
+ *   hist[c]= #{b : idx[b]==c}                              (quantizer.py:64)
+ *   loss = (1+beta)*sqerr/(B*D); perplexity = exp(-sum p log(p+1e-10)), p = hist/B  (:57-58,:64-65)
+ *
+ * dtype CEEG_F32 : z,z_q fp32; distance GEMM on v_mfma_f32_16x16x4_f32.  dot is the k-ascending
+ *                  fmaf chain from 0 (bit-identical to oracle/ceeg_oracle.c:vq_forward_f32).
+ * dtype CEEG_BF16: z,z_q bf16 (codebook stays fp32, rounded RNE to bf16 for the GEMM);
+ *                  v_mfma_f32_16x16x32_bf16, fp32 accumulate; score = dot - ee/2 (row-constant zz
+ *                  dropped); no reference counterpart.
+ *
+ * z [B,D], W [n_e,D] fp32, z_q [B,D] (dtype), idx [B] int64, loss/perplexity: 1 float each (device),
+ * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 65536, B >= 0.
+ * B == 0 writes loss = NaN-free zeros? No: B == 0 is CEEG_EINVAL (the reference divides by zero).
+ * ----------------------------------------------------------------------------------------------*/
+size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype);
+int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
+                    void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
+                    void* ws, size_t ws_bytes, void* stream);
+
+/* Backward of A2 (closed form; autograd of quantizer.py:54-61):
+ *   dz[b]  = g[b] + s*(2/(B*D))*(z[b]-W[idx[b]])              g = dL/dz_q (NULL = 0), s = dL/dloss
+ *   dW[c]  = s*beta*(2/(B*D)) * sum_{b: idx[b]==c} (W[c]-z[b])   (deterministic segmented sum)
+ * s is read from DEVICE memory (*s_dev, 1 float) so autograd never syncs.  dz (dtype) and/or dW (fp32)
+ * may be NULL to skip. */
+size_t ceeg_vq_backward_ws_bytes(int64_t B, int n_e, int D, int dtype);
+int ceeg_vq_backward(const void* z, const float* W, const int64_t* idx, const void* g, const float* s_dev,
+                     int64_t B, int n_e, int D, int dtype, float beta, void* dz, float* dW,
+                     void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A5  GCNConv / gcn_norm — upstream torch_geometric (un-vendored, unpinned: environment.yml:13);
+ *     edge direction old_id -> new_id as built at scripts/dataset.py:147-153,217-224.
+ *
+ * ceeg_csr_build: edge list (src[e] -> dst[e], int64, PyG edge_index rows 0 and 1) -> CSR grouped by
+ *   dst, entries ordered by (dst, src, original edge id): THE canonical edge order.  With
+ *   self_loops=1 it applies add_remaining_self_loops: every existing self-loop is dropped and exactly
+ *   one (i,i) entry per node is added (perm = -1-i ... see below).  Outputs:
+ *     rowptr [N+1] int32, col [nnz] int32 (source node), perm [nnz] int32 (original edge id, or -1 for
+ *     an added self-loop), nnz_out: 1 int64 on the DEVICE.  nnz upper bound = E + (self_loops ? N : 0):
+ *     col/perm must have that capacity.
+ * ceeg_csr_transpose: CSR (rows=dst) -> CSR of the transpose (rows=src), entries ordered by
+ *   (src, dst, position); tperm[q] = position p in the input CSR, so values permute as val_t[q]=val[tperm[q]].
+ * ceeg_gcn_norm: val[p] = dinv[col[p]] * w[p] * dinv[row(p)], deg[i] = sum_{p in row i} w[p]
+ *   (in-degree at the target incl. the self-loop), dinv = deg^-1/2 (0 where deg == 0).  w == NULL means
+ *   all ones; else w[p] = ew[perm[p]] for real edges and 1 for added self-loops (ew: [E] fp32).
+ * ----------------------------------------------------------------------------------------------*/
+size_t ceeg_csr_build_ws_bytes(int64_t E, int64_t N, int self_loops);
+int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int self_loops,
+                   int32_t* rowptr, int32_t* col, int32_t* perm, int64_t* nnz_out,
+                   void* ws, size_t ws_bytes, void* stream);
+size_t ceeg_csr_transpose_ws_bytes(int64_t nnz, int64_t N);
+int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, int64_t N,
+                       int32_t* t_rowptr, int32_t* t_col, int32_t* t_perm,
+                       void* ws, size_t ws_bytes, void* stream);
+int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew,
+                  int64_t nnz, int64_t N, float* deg_inv_sqrt, float* val, void* stream);
+
+/* Deterministic CSR segmented SpMM (the GCNConv aggregation and every transposed/backward pass):
+ *   out[i,:] = act( sum_{p=rowptr[i]}^{rowptr[i+1]-1} v(p) * X[col[p],:]  + bias )      i in [0,N)
+ *   v(p) = val[p]            if vperm == NULL
+ *        = val[vperm[p]]     otherwise (values kept in the order of ANOTHER structure, e.g. the CSC pass)
+ * Summation order is p ascending in fixed blocks (SPMM_CHUNK) whose partial sums are added in block order
+ * -> bitwise reproducible, no atomics.  X [*,ldx] fp32, out [N,ldo] fp32, F % 4 == 0, 4 <= F <= 1024,
+ * ldx/ldo multiples of 4, pointers 16-byte aligned.  bias [F] or NULL; relu != 0 applies max(.,0).
+ * accumulate != 0 adds into `out` instead of overwriting it. */
+size_t ceeg_spmm_ws_bytes(int64_t N, int64_t nnz, int F);
+int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                  const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                  int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A3+A4  VGAE.reparametrize + VGAE.kl_loss (upstream PyG; anchors: MAX_LOGSTD scripts/run.py:13,
+ *        BaseCVAE.reparameterize scripts/models.py:38-43), fused in one pass.
+ *   ls = min(logstd, max_logstd);  z = mu + eps*exp(ls)   (log_var != 0: z = mu + eps*exp(0.5*ls),
+ *        the in-repo models.py:40 variant)
+ *   kl = -0.5/N * sum_{n,d} (1 + 2*ls - mu^2 - exp(2*ls))
+ * mu, logstd: [N,D] fp32 views with row strides ld_mu/ld_ls (so the fused [N,2D] SpMM output is read in
+ * place).  eps: [N,D] fp32 explicit noise, or NULL -> Philox4x32-10(seed, element index) + Box-Muller,
+ * restated bit-for-bit (integers) in oracle/ceeg_oracle.c.  training == 0: z = mu (eval).
+ * kl: 1 float on the device.
+ * Backward: dmu = gz + gkl*mu/N ; dlogstd = [logstd<=max] * (gz*eps*exp(ls) + gkl*(exp(2ls)-1)/N). */
+size_t ceeg_reparam_kl_ws_bytes(int64_t N, int D);
+int ceeg_reparam_kl_fwd(const float* mu, int64_t ld_mu, const float* logstd, int64_t ld_ls, const float* eps,
+                        uint64_t seed, int64_t N, int D, float max_logstd, int log_var, int training,
+                        float* z, float* kl, void* ws, size_t ws_bytes, void* stream);
+int ceeg_reparam_kl_bwd(const float* mu, int64_t ld_mu, const float* logstd, int64_t ld_ls, const float* eps,
+                        uint64_t seed, const float* gz, const float* gkl_dev, int64_t N, int D,
+                        float max_logstd, int log_var, int training,
+                        float* dmu, int64_t ld_dmu, float* dlogstd, int64_t ld_dls, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A6  InnerProductDecoder.forward + GAE.recon_loss (upstream PyG), literal "+EPS" form, EPS = 1e-15:
+ *   v_e = <z[i_e], z[j_e]> ; pos: -log(sigmoid(v)+EPS) ; neg: -log(1-sigmoid(v)+EPS)
+ * Edge-list form (any edge order; used for user-supplied pos/neg edge_index):
+ *   i,j: [E] int32 node ids.  negative != 0 selects the neg term.  Outputs: coef[e] = d(term_e)/dv_e
+ *   (fp32, unscaled), loss_sum: 1 float (device) = sum_e term_e  (the caller divides by E: mean),
+ *   optionally prob[e] = sigmoid(v_e) (decoder(z, edge_index, sigmoid=True)).
+ * The backward  dz[n] = sum_{e: i_e=n} c_e z[j_e] + sum_{e: j_e=n} c_e z[i_e]  is two ceeg_spmm_csr calls
+ * over the edge list's CSR and its transpose (val = coef via perm) — atomics-free by construction. */
+size_t ceeg_edge_bce_ws_bytes(int64_t E, int D);
+int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32_t* j, int64_t E, int D,
+                      int negative, float* coef, float* prob, float* loss_sum,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* Fused CSR-ordered decoder with permutation-structured negatives (the trainer's fast path):
+ * for CSR row r (= dst) and entry p (src = col[p]):
+ *   positive pair (col[p], r);   negative pair (col[p], sigma(r)), sigma(x) = (a*x + b) mod N, gcd(a,N)=1.
+ *   A negative is INVALID (masked out, coef 0) when col[p]==sigma(r) or (col[p] -> sigma(r)) is an edge
+ *   (binary search in row sigma(r), rows being src-sorted).
+ * One gather of z[col[p]] serves both dots.  Outputs coef_pos[nnz], coef_neg[nnz] (unscaled d term/dv),
+ * sums[0]=sum pos terms, sums[1]=sum valid neg terms, sums[2]=number of valid negatives (as float),
+ * all written to `sums` (3 floats, device).  rowptr/col: CSR WITHOUT self-loops (ceeg_csr_build
+ * self_loops=0). */
+size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
+int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b,
+                           float* coef_pos, float* coef_neg, float* sums,
+                           void* ws, size_t ws_bytes, void* stream);
+/* Backward of the fused decoder: dz[n] = gp * (pos terms) + gn * (neg terms) where gp/gn are read from
+ * the device (gscale[0], gscale[1]: upstream grad times 1/E_pos resp. 1/n_valid_neg).
+ *   dz[n] = sum_{p in row n} gp*cp[p] z[col p]                 (n as dst of positives)
+ *         + sum_{q in trow n} gp*cp[tperm q] z[tcol q]         (n as src of positives)
+ *         + sum_{p in row sigma^-1(n)} gn*cn[p] z[col p]       (n as negative endpoint sigma(r))
+ *         + sum_{q in trow n} gn*cn[tperm q] z[sigma(tcol q)]  (n as src of negatives)
+ * sig_ainv = a^-1 mod N. */
+int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+                           const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
+                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                           const float* coef_pos, const float* coef_neg, const float* gscale,
+                           float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+
+/* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
+ * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
+ * when src==dst or src->dst is an edge of the given CSR (rows=dst, src-sorted), up to 16 attempts; a
+ * sample that never succeeds is written as (-1,-1).  Bit-exact restatement: oracle/ceeg_oracle.c. */
+int ceeg_neg_sample_uniform(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
+                            int32_t* neg_src, int32_t* neg_dst, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CEEG_H */

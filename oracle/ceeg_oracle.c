@@ -1,0 +1,167 @@
+/*
+ * ceeg_oracle.c — CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the bit-exact parts of the hot path, used only by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg as the CHECKER.  The product
+ * path (causal_eeg_vae_amd/) never links, imports or calls anything in oracle/.
+ *
+ * Pinned against the reference: vq_forward_f32 is checked against golden vectors generated
+ * from the live /root/reference/scripts/quantizer.py (tests/golden/make_vq_golden.py,
+ * tests/test_oracle_golden.py).  The Philox / negative-sampling parts have no reference
+ * counterpart (upstream PyG uses python `random`): "parity unpinned", they pin the HIP
+ * kernels' integer streams only.
+ *
+ * Build: make -C oracle   (gcc -O2 -ffp-contract=off: every fused multiply-add below is an
+ * explicit fmaf(), nothing is contracted or re-associated behind our back).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------
+ * VectorQuantizer.forward, fp32 — follows scripts/quantizer.py:43-65 line by line, with the
+ * SPECIFIED accumulation order (SURVEY.md §7 hard part 1):
+ *   zz[b]   = fmaf-chain over k ascending of z[b,k]^2            (quantizer.py:43  torch.sum(z**2))
+ *   ee[c]   = fmaf-chain over k ascending of W[c,k]^2            (quantizer.py:44  torch.sum(W**2))
+ *   dot     = fmaf-chain over k ascending of z[b,k]*W[c,k], from 0 (quantizer.py:45 matmul)
+ *   d       = fl( fl(zz+ee) - 2*dot )  == fmaf(-2, dot, zz+ee)    (quantizer.py:43-45)
+ *   idx[b]  = first c attaining the minimum                       (quantizer.py:48, torch.argmin
+ *             on CPU returns the lowest index on ties — SURVEY.md §8(c))
+ *   z_q[b]  = W[idx[b]]                                           (quantizer.py:49-54)
+ *   loss    = mean((z_q-z)^2) + beta*mean((z_q-z)^2)              (quantizer.py:57-58)
+ *   ppl     = exp(-sum_c p log(p+1e-10)), p = hist/B              (quantizer.py:64-65)
+ * v_mfma_f32_16x16x4_f32 is a k-ordered fmaf chain, so the HIP kernel reproduces `dot` bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+void oracle_vq_forward_f32(const float* z, const float* W, int64_t B, int n_e, int D, float beta,
+                           float* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
+                           float* dmin_out /* [B] or NULL: the winning distance */) {
+  float* ee = (float*)malloc(sizeof(float) * (size_t)n_e);
+  for (int c = 0; c < n_e; ++c) {
+    float e = 0.f;
+    for (int k = 0; k < D; ++k) e = fmaf(W[(size_t)c * D + k], W[(size_t)c * D + k], e);
+    ee[c] = e;
+  }
+  memset(hist, 0, sizeof(uint32_t) * (size_t)n_e);
+  double sq = 0.0;
+  for (int64_t b = 0; b < B; ++b) {
+    const float* zb = z + (size_t)b * D;
+    float zz = 0.f;
+    for (int k = 0; k < D; ++k) zz = fmaf(zb[k], zb[k], zz);
+    float best = INFINITY;
+    int bi = 0;
+    for (int c = 0; c < n_e; ++c) {
+      const float* w = W + (size_t)c * D;
+      float dot = 0.f;
+      for (int k = 0; k < D; ++k) dot = fmaf(zb[k], w[k], dot);
+      float d = fmaf(-2.0f, dot, zz + ee[c]);
+      if (d < best) { best = d; bi = c; }
+    }
+    idx[b] = bi;
+    hist[bi]++;
+    if (dmin_out) dmin_out[b] = best;
+    for (int k = 0; k < D; ++k) {
+      float q = W[(size_t)bi * D + k];
+      z_q[(size_t)b * D + k] = q;
+      double df = (double)q - (double)zb[k];
+      sq += df * df;
+    }
+  }
+  double m = sq / ((double)B * (double)D);
+  *loss = (float)(m + (double)beta * m);
+  double ent = 0.0;
+  for (int c = 0; c < n_e; ++c) {
+    float p = (float)hist[c] / (float)B; /* torch.mean of a 0/1 fp32 column */
+    ent += (double)(p * logf(p + 1e-10f));
+  }
+  *perplexity = (float)exp(-ent);
+  free(ee);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Philox4x32-10 (Salmon et al., SC'11) — counter-based RNG shared by the reparametrisation noise
+ * and the uniform negative sampler.  No reference counterpart (torch.randn_like at
+ * scripts/models.py:41 / python random in upstream PyG cannot be matched): parity unpinned;
+ * this restatement pins the HIP kernels' integer streams bit for bit.
+ * ---------------------------------------------------------------------------------------- */
+static inline void philox_round(uint32_t c[4], uint32_t k[2]) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+void oracle_philox4x32_10(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t out[4]) {
+  uint32_t c[4] = {c0, c1, c2, c3};
+  uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k);
+    k[0] += 0x9E3779B9u;
+    k[1] += 0xBB67AE85u;
+  }
+  memcpy(out, c, sizeof(uint32_t) * 4);
+}
+
+#define CEEG_TAG_EPS 0x45505300u /* 'EPS\0' */
+#define CEEG_TAG_NEG 0x4E454700u /* 'NEG\0' */
+
+/* eps[e], e = flat element index: group g = e>>2 draws Philox(seed; g_lo, g_hi, TAG_EPS, 0) = x0..x3,
+ * u_i = (x_i + 1) * 2^-32 in (0,1];  r = sqrt(-2 ln u0), t = 2 pi u1 -> (r cos t, r sin t); same for
+ * (x2,x3).  Integer stream bit-exact; the float transcendentals differ from the GPU's by a few ulp. */
+void oracle_philox_normal(uint64_t seed, int64_t n, float* eps) {
+  for (int64_t g = 0; g * 4 < n; ++g) {
+    uint32_t x[4];
+    oracle_philox4x32_10(seed, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), CEEG_TAG_EPS, 0u, x);
+    float v[4];
+    for (int h = 0; h < 2; ++h) {
+      float u0 = ((float)x[2 * h] + 1.0f) * 2.3283064365386963e-10f;
+      float u1 = ((float)x[2 * h + 1] + 1.0f) * 2.3283064365386963e-10f;
+      if (u0 > 1.0f) u0 = 1.0f;
+      float r = sqrtf(-2.0f * logf(u0));
+      float t = 6.283185307179586f * u1;
+      v[2 * h] = r * cosf(t);
+      v[2 * h + 1] = r * sinf(t);
+    }
+    for (int i = 0; i < 4 && g * 4 + i < n; ++i) eps[g * 4 + i] = v[i];
+  }
+}
+
+void oracle_philox_raw(uint64_t seed, int64_t ngroups, uint32_t tag, uint32_t* out /* [ngroups*4] */) {
+  for (int64_t g = 0; g < ngroups; ++g)
+    oracle_philox4x32_10(seed, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), tag, 0u, out + 4 * g);
+}
+
+/* is (s -> d) an entry of the CSR (rows = dst, cols src-sorted)? */
+static int csr_has(const int32_t* rowptr, const int32_t* col, int32_t d, int32_t s) {
+  int lo = rowptr[d], hi = rowptr[d + 1];
+  while (lo < hi) {
+    int mid = (lo + hi) >> 1;
+    if (col[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  return lo < rowptr[d + 1] && col[lo] == s;
+}
+
+/* Uniform negative sampler (ceeg_neg_sample_uniform): sample k tries attempt = 0..15 with
+ * x = Philox(seed; k_lo, k_hi, TAG_NEG, attempt); src = (x0*N)>>32, dst = (x1*N)>>32;
+ * rejected when src==dst or src->dst is an edge.  Never-accepted samples are (-1,-1). */
+void oracle_neg_sample_uniform(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
+                               int32_t* neg_src, int32_t* neg_dst) {
+  for (int64_t k = 0; k < num; ++k) {
+    int32_t s = -1, d = -1;
+    for (uint32_t a = 0; a < 16; ++a) {
+      uint32_t x[4];
+      oracle_philox4x32_10(seed, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), CEEG_TAG_NEG, a, x);
+      int32_t cs = (int32_t)(((uint64_t)x[0] * (uint64_t)N) >> 32);
+      int32_t cd = (int32_t)(((uint64_t)x[1] * (uint64_t)N) >> 32);
+      if (cs == cd) continue;
+      if (csr_has(rowptr, col, cd, cs)) continue;
+      s = cs; d = cd;
+      break;
+    }
+    neg_src[k] = s;
+    neg_dst[k] = d;
+  }
+}
