@@ -1,0 +1,111 @@
+"""GPU parity: CSR build / transpose / gcn_norm / SpMM / samplers through the C-ABI vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_graph(N, E, seed, loops=True, hubs=0):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    if hubs:
+        src[: hubs] = 3          # a source hub (long row in the transpose)
+        dst[hubs: 2 * hubs] = 5  # a destination hub (long row in the CSR)
+    if loops:
+        src[-7:] = dst[-7:]      # a few pre-existing self-loops, one duplicated
+        src[-1] = src[-2]; dst[-1] = dst[-2]
+    return src.astype(np.int64), dst.astype(np.int64)
+
+
+@pytest.mark.parametrize("N,E,self_loops,hubs", [(50, 300, True, 0), (50, 300, False, 0), (1000, 20000, True, 700),
+                                                 (4000, 3000, True, 0), (7, 0, True, 0), (100000, 1600000, True, 5000)])
+def test_csr_build_transpose_bit_exact(N, E, self_loops, hubs):
+    from causal_eeg_vae_amd import CsrPair
+    from oracle import ref_torch
+    src, dst = _rand_graph(N, E, N + E, loops=E > 10, hubs=hubs)
+    ei = torch.from_numpy(np.stack([src, dst])).cuda()
+    p = CsrPair(ei, N, self_loops)
+    rowptr, col, perm = ref_torch.csr_build_np(src, dst, N, self_loops)
+    assert p.nnz == rowptr[-1]
+    np.testing.assert_array_equal(p.rowptr.cpu().numpy(), rowptr)
+    np.testing.assert_array_equal(p.col.cpu().numpy(), col)
+    np.testing.assert_array_equal(p.perm.cpu().numpy(), perm)
+    t_rowptr, t_col, t_perm = ref_torch.csr_transpose_np(rowptr, col, N)
+    np.testing.assert_array_equal(p.t_rowptr.cpu().numpy(), t_rowptr)
+    np.testing.assert_array_equal(p.t_col.cpu().numpy(), t_col)
+    np.testing.assert_array_equal(p.t_perm.cpu().numpy(), t_perm)
+    # sortedness property (the canonical (dst, src) order)
+    key = np.repeat(np.arange(N), np.diff(rowptr)) * (N + 1) + p.col.cpu().numpy()
+    assert (np.diff(key) >= 0).all()
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_gcn_norm(weighted):
+    from causal_eeg_vae_amd import EventGraph
+    from oracle import ref_torch
+    N, E = 3000, 40000
+    src, dst = _rand_graph(N, E, 11, hubs=900)
+    ew = np.random.default_rng(1).uniform(0.5, 5.0, E).astype(np.float32) if weighted else None
+    g = EventGraph(torch.from_numpy(np.stack([src, dst])).cuda(), N, None if ew is None else torch.from_numpy(ew).cuda())
+    rowptr, col, perm = ref_torch.csr_build_np(src, dst, N, True)
+    dinv, val = ref_torch.gcn_norm_np(rowptr, col, perm, ew, N)
+    np.testing.assert_allclose(g.dinv.cpu().numpy(), dinv, rtol=1e-5)
+    np.testing.assert_allclose(g.gcn_val.cpu().numpy(), val, rtol=1e-5)
+
+
+@pytest.mark.parametrize("F", [4, 8, 40, 128, 256, 512])
+def test_spmm_vs_oracle_and_determinism(F):
+    from causal_eeg_vae_amd import EventGraph
+    from causal_eeg_vae_amd.models import _spmm
+    from oracle import ref_torch
+    N, E = 5000, 80000
+    src, dst = _rand_graph(N, E, F, hubs=3000)  # rows of 3000 entries: exercises the long-row split (chunk 256)
+    g = EventGraph(torch.from_numpy(np.stack([src, dst])).cuda(), N)
+    x = torch.randn(N, F, device="cuda")
+    bias = torch.randn(F, device="cuda")
+    rowptr, col, perm = ref_torch.csr_build_np(src, dst, N, True)
+    _, val = ref_torch.gcn_norm_np(rowptr, col, perm, None, N)
+    out = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, x, N, bias=bias)
+    ref = ref_torch.spmm_np(rowptr, col, val, x.cpu().numpy()) + bias.cpu().numpy().astype(np.float64)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * scale)
+    out2 = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, x, N, bias=bias)
+    assert torch.equal(out, out2)  # bitwise reproducible
+    # transposed pass with permuted values == A^T x
+    t_rowptr, t_col, t_perm = ref_torch.csr_transpose_np(rowptr, col, N)
+    outT = _spmm(g.gcn.t_rowptr, g.gcn.t_col, g.gcn_val, g.gcn.t_perm, x, N, relu=True)
+    refT = np.maximum(ref_torch.spmm_np(t_rowptr, t_col, val[t_perm], x.cpu().numpy()), 0)
+    np.testing.assert_allclose(outT.cpu().numpy(), refT, rtol=1e-5, atol=1e-6 * np.abs(refT).max())
+    # linearity: A(2x + y) == 2 A x + A y
+    y = torch.randn(N, F, device="cuda")
+    lhs = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, 2 * x + y, N)
+    rhs = 2 * _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, x, N) + _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, y, N)
+    torch.testing.assert_close(lhs, rhs, rtol=1e-4, atol=1e-4)
+
+
+def test_negative_sampling_bit_exact():
+    from causal_eeg_vae_amd import negative_sampling, CsrPair
+    from oracle import c_oracle, ref_torch
+    N, E = 200, 6000  # dense enough that rejections happen
+    src, dst = _rand_graph(N, E, 5, loops=False)
+    ei = torch.from_numpy(np.stack([src, dst])).cuda()
+    neg = negative_sampling(ei, N, 5000, seed=77)
+    rowptr, col, _ = ref_torch.csr_build_np(src, dst, N, False)
+    s, d = c_oracle.neg_sample_uniform(rowptr, col, N, 5000, 77)
+    keep = s >= 0
+    np.testing.assert_array_equal(neg.cpu().numpy(), np.stack([s[keep], d[keep]]))
+    edges = set(zip(src.tolist(), dst.tolist()))
+    assert all((a, b) not in edges and a != b for a, b in neg.t().tolist())
+
+
+def test_philox_eps_matches_oracle():
+    from causal_eeg_vae_amd.models import _ReparamKL
+    from oracle import c_oracle
+    N, D = 1000, 64
+    mu = torch.zeros(N, D, device="cuda"); ls = torch.zeros(N, D, device="cuda")
+    z, kl = _ReparamKL.apply(mu, ls, None, 4242, True, False)  # z = eps exactly
+    eps = c_oracle.philox_normal(4242, N * D).reshape(N, D)
+    np.testing.assert_allclose(z.cpu().numpy(), eps, rtol=2e-4, atol=2e-5)
+    assert abs(kl.item()) < 1e-6

@@ -1,0 +1,167 @@
+"""GPU parity: reparam+KL, decoder (edge-list and fused), GCNConv, and the full VGAE+VQ step vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(a, b, rtol=1e-5, atol_rel=1e-6):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_rel * max(np.abs(b).max(), 1e-30))
+
+
+def _graph(N, E, seed):
+    rng = np.random.default_rng(seed)
+    dst = rng.integers(1, N, 2 * E)
+    src = (dst * rng.random(2 * E) ** 2).astype(np.int64)  # DAG, src < dst, early nodes are hubs
+    key = np.unique(dst * N + src)[:E]
+    rng.shuffle(key)
+    return np.stack([key % N, key // N]).astype(np.int64)
+
+
+@pytest.mark.parametrize("N,D,fused,training", [(1000, 128, True, True), (333, 20, False, True), (257, 7, False, True), (500, 64, True, False)])
+def test_reparam_kl_fwd_bwd(N, D, fused, training):
+    from causal_eeg_vae_amd.models import _ReparamKL
+    from oracle import ref_torch
+    torch.manual_seed(N)
+    ml = torch.randn(N, 2 * D) * 2
+    ml[::7, D:] = 11.5  # exercise the MAX_LOGSTD clamp (zero gradient there)
+    eps = torch.randn(N, D)
+    w = torch.randn(N, D)
+    a = ml.clone().requires_grad_(True)
+    mu, ls = a[:, :D], a[:, D:].clamp(max=ref_torch.MAX_LOGSTD)
+    z_ref = ref_torch.reparametrize(mu, ls, eps) if training else mu
+    kl_ref = ref_torch.kl_loss(mu, ls)
+    ((z_ref * w).sum() + 3.0 * kl_ref).backward()
+    b = ml.clone().cuda().requires_grad_(True)
+    if fused:
+        z, kl = _ReparamKL.apply(b, None, eps.cuda(), 0, training, False)
+    else:
+        z, kl = _ReparamKL.apply(b[:, :D], b[:, D:], eps.cuda(), 0, training, False)
+    ((z * w.cuda()).sum() + 3.0 * kl).backward()
+    _close(z, z_ref)
+    _close(kl, kl_ref)
+    _close(b.grad, a.grad, rtol=2e-5)
+
+
+def test_reparam_log_var_variant():
+    from causal_eeg_vae_amd.models import _ReparamKL
+    mu = torch.randn(64, 16); lv = torch.randn(64, 16); eps = torch.randn(64, 16)
+    z, _ = _ReparamKL.apply(mu.cuda(), lv.cuda(), eps.cuda(), 0, True, True)
+    _close(z, mu + eps * torch.exp(0.5 * lv))  # scripts/models.py:38-43
+
+
+@pytest.mark.parametrize("D", [128, 16, 256])
+def test_edge_bce_and_recon_loss(D):
+    from causal_eeg_vae_amd import VGAE, InnerProductDecoder
+    from oracle import ref_torch
+    N, E = 2000, 30000
+    ei = torch.from_numpy(_graph(N, E, D))
+    neg = torch.from_numpy(np.random.default_rng(D).integers(0, N, (2, E)))
+    z0 = torch.randn(N, D) * (2.0 / D ** 0.5)
+    z0[:5] *= 12  # saturate some sigmoids: the literal +EPS form must match
+    a = z0.clone().requires_grad_(True)
+    ref_torch.recon_loss(a, ei, neg).backward()
+    b = z0.clone().cuda().requires_grad_(True)
+    model = VGAE(torch.nn.Identity())
+    loss = model.recon_loss(b, ei.cuda(), neg.cuda())
+    loss.backward()
+    _close(loss, ref_torch.recon_loss(z0, ei, neg))
+    _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+    p = InnerProductDecoder()(b.detach(), ei.cuda())
+    _close(p, ref_torch.decode(z0, ei), rtol=1e-5, atol_rel=1e-6)
+
+
+@pytest.mark.parametrize("N,E,D", [(3000, 50000, 128), (500, 20000, 32)])
+def test_fused_decoder_vs_oracle(N, E, D):
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    from oracle import ref_torch
+    ei_np = _graph(N, E, N)
+    g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    a_, b_, ainv = sigma_params(N, 3, 17)
+    assert (a_ * ainv) % N == 1
+    rowptr, col, perm = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, sig, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_)
+    assert 0 < (~valid).sum() < len(valid) or N > 1000  # the dense case must exercise the collision mask
+    z0 = torch.randn(N, D) * (2.0 / D ** 0.5)
+    a = z0.clone().requires_grad_(True)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
+    neg_ei = torch.from_numpy(np.stack([s, sig]).astype(np.int64))[:, torch.from_numpy(valid)]
+    ref = ref_torch.recon_loss(a, pos_ei, neg_ei)
+    (ref * 1.7).backward()
+    b = z0.clone().cuda().requires_grad_(True)
+    rec, sums = _FusedDecoder.apply(b, g, a_, b_, ainv)
+    (rec * 1.7).backward()
+    assert int(sums[2].item()) == int(valid.sum())  # valid-negative count is exact
+    _close(rec, ref)
+    _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+    rec2, _ = _FusedDecoder.apply(b, g, a_, b_, ainv)
+    assert torch.equal(rec, rec2)
+
+
+def test_gcnconv_fwd_bwd_and_state_dict():
+    from causal_eeg_vae_amd import GCNConv, EventGraph
+    from oracle import ref_torch
+    N, E, Fi, Fo = 3000, 40000, 48, 128
+    ei = torch.from_numpy(_graph(N, E, 1))
+    ei = torch.cat([ei, torch.tensor([[5, 5, 9], [5, 5, 9]])], dim=1)  # pre-existing (duplicated) self-loops
+    ew = torch.rand(ei.shape[1]) + 0.5
+    ref = ref_torch.RefGCNConv(Fi, Fo)
+    with torch.no_grad():
+        ref.bias.normal_()
+    conv = GCNConv(Fi, Fo).cuda()
+    conv.load_state_dict(ref.state_dict())  # same keys: lin.weight, bias
+    x = torch.randn(N, Fi)
+    for w in (None, ew):
+        a = x.clone().requires_grad_(True)
+        out_ref = ref(a, ei, w)
+        out_ref.square().sum().backward()
+        b = x.clone().cuda().requires_grad_(True)
+        g = EventGraph(ei.cuda(), N, None if w is None else w.cuda())
+        out = conv(b, g)
+        out.square().sum().backward()
+        _close(out, out_ref)
+        _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+        _close(conv.lin.weight.grad, ref.lin.weight.grad, rtol=1e-4, atol_rel=1e-5)
+        _close(conv.bias.grad, ref.bias.grad, rtol=1e-4, atol_rel=1e-5)
+        conv.zero_grad(); ref.zero_grad()
+
+
+def test_full_step_vs_oracle():
+    """GCN-VGAE + VQ training step: loss, code indices and every parameter gradient vs the CPU restatement."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
+    from oracle import ref_torch
+    N, E, Fi, D, n_e = 4000, 64000, 32, 16, 64
+    ei_np = _graph(N, E, 2)
+    torch.manual_seed(0)
+    ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = VGAEVQ(Fi, D, n_e, 0.25).cuda()
+    model.load_state_dict(ref.state_dict())
+    x = torch.randn(N, Fi)
+    eps = torch.randn(N, D)
+    sig = sigma_params(N, 0, 5)
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, sg, valid = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1])
+    neg_ei = torch.from_numpy(np.stack([s, sg]).astype(np.int64))
+    ei = torch.from_numpy(ei_np)
+    loss_ref, aux_ref = ref(x, ei, eps, neg_ei, torch.from_numpy(valid))
+    loss_ref.backward()
+    g = EventGraph(ei.cuda(), N)
+    loss, aux = model(x.cuda(), g, step=5, eps=eps.cuda(), sigma=sig)
+    loss.backward()
+    _close(aux["z"], aux_ref["z"], rtol=1e-4, atol_rel=1e-5)
+    same = (aux["idx"].cpu() == aux_ref["idx"])
+    assert same.double().mean() > 0.999  # z differs by fp32 rounding between the two encoders: near-ties may flip
+    for k in ("kl", "rec", "vq"):
+        _close(aux[k], aux_ref[k], rtol=1e-4)
+    _close(loss, loss_ref, rtol=1e-4)
+    if bool(same.all()):
+        ref_params = dict(ref.named_parameters())
+        for name, p in model.named_parameters():
+            _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)

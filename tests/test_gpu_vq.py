@@ -1,0 +1,141 @@
+"""GPU parity: VectorQuantizer through the C-ABI (libceeg.so) vs the oracle and the reference golden vectors."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "vq_*.npz")))
+
+
+def _mod(n_e, D, beta, W, one_hot=True):
+    from causal_eeg_vae_amd import VectorQuantizer
+    vq = VectorQuantizer(n_e, D, beta, return_one_hot=one_hot).cuda()
+    with torch.no_grad():
+        vq.embedding.weight.copy_(torch.as_tensor(W))
+    return vq
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[3:-4] for p in CASES])
+def test_fp32_golden_and_oracle(path):
+    from oracle import c_oracle
+    g = np.load(path)
+    n_e, D = g["W"].shape
+    beta = float(g["beta"])
+    vq = _mod(n_e, D, beta, g["W"])
+    z = torch.from_numpy(g["z"]).cuda().requires_grad_(True)
+    loss, z_q, ppl, onehot, idx = vq(z)
+    (loss + (z_q * torch.from_numpy(g["r"]).cuda()).sum()).backward()
+    # return-type fidelity (quantizer.py:67)
+    assert idx.dtype == torch.int64 and idx.shape == (z.shape[0], 1)
+    assert onehot.shape == (z.shape[0], n_e) and onehot.dtype == torch.float32
+    assert loss.dim() == 0 and ppl.dim() == 0
+    o = c_oracle.vq_forward_f32(g["z"], g["W"], beta)
+    gi = idx[:, 0].cpu().numpy()
+    np.testing.assert_array_equal(gi, o["idx"])  # bit-exact vs the CPU restatement (specified fmaf-chain order)
+    assert torch.equal(onehot.argmax(1), idx[:, 0])
+    np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ppl.item(), o["perplexity"], rtol=1e-5)
+    ref_idx = g["idx"][:, 0]
+    if (gi == ref_idx).all():  # same indices as the literal reference: every float output must match it too
+        np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(ppl.item(), g["perplexity"], rtol=1e-5)
+        np.testing.assert_allclose(z_q.detach().cpu().numpy(), g["z_q"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z.grad.cpu().numpy(), g["dz"], rtol=1e-5, atol=1e-6 * np.abs(g["dz"]).max())
+        np.testing.assert_allclose(vq.embedding.weight.grad.cpu().numpy(), g["dW"], rtol=1e-5, atol=1e-6 * max(np.abs(g["dW"]).max(), 1e-30))
+    else:  # rounding-sensitive rows only (top-2 gap below a few ulp of the distance magnitude)
+        bad = np.nonzero(gi != ref_idx)[0]
+        assert len(bad) <= max(1, len(gi) // 50)
+        assert (g["gap64"][bad] < 1e-4).all()
+
+
+@pytest.mark.parametrize("B,n_e,D,init", [(5000, 512, 256, "normal"), (5000, 512, 256, "ref"), (3001, 512, 128, "normal"),
+                                          (1000, 512, 8, "ref"), (777, 100, 24, "normal"), (130, 33, 200, "normal")])
+def test_fp32_random_bit_exact_vs_oracle(B, n_e, D, init):
+    from oracle import c_oracle
+    rng = np.random.default_rng(B + n_e + D)
+    W = rng.standard_normal((n_e, D)).astype(np.float32) if init == "normal" else \
+        rng.uniform(-1.0 / n_e, 1.0 / n_e, (n_e, D)).astype(np.float32)
+    zn = rng.standard_normal((B, D)).astype(np.float32)
+    vq = _mod(n_e, D, 0.25, W, one_hot=False)
+    loss, z_q, ppl, onehot, idx = vq(torch.from_numpy(zn).cuda())
+    assert onehot is None
+    o = c_oracle.vq_forward_f32(zn, W, 0.25)
+    np.testing.assert_array_equal(idx[:, 0].cpu().numpy(), o["idx"])
+    np.testing.assert_array_equal(z_q.detach().cpu().numpy(), o["z_q"])
+    np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-5)
+    np.testing.assert_allclose(ppl.item(), o["perplexity"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,n_e,D", [(4096, 512, 256), (1000, 512, 128), (300, 96, 40), (64, 512, 8)])
+def test_bf16_indices_within_rounding_bound(B, n_e, D):
+    from oracle import ref_torch
+    torch.manual_seed(B + D)
+    W = torch.randn(n_e, D)
+    z = torch.randn(B, D).to(torch.bfloat16)
+    vq = _mod(n_e, D, 0.25, W.numpy(), one_hot=False)
+    zc = z.cuda().requires_grad_(True)
+    loss, z_q, ppl, _, idx = vq(zc)
+    assert z_q.dtype == torch.bfloat16
+    sc = ref_torch.vq_bf16_scores64(z, W)
+    best = sc.argmax(1)
+    gi = idx[:, 0].cpu()
+    got = sc.gather(1, gi[:, None])[:, 0]
+    top = sc.max(1).values
+    # fp32 accumulation of 256 exact bf16 products: |error| <= ~D * 2^-24 * sum|a b|; indices must be optimal within it
+    bound = 4 * D * 2.0 ** -24 * (z.double().abs() @ W.to(torch.bfloat16).double().abs().t()).max(1).values
+    assert ((top - got) <= bound).all()
+    assert (gi == best).double().mean() > 0.999
+    zq_ref = W[gi].to(torch.bfloat16)
+    assert torch.equal(z_q.cpu(), zq_ref)
+    m = ((W[gi].double() - z.double()) ** 2).mean()
+    np.testing.assert_allclose(loss.item(), float(1.25 * m), rtol=1e-2)
+    (loss + z_q.float().sum()).backward()
+    dz_ref = 1.0 + 2.0 / (B * D) * (z.double() - W[gi].double())
+    np.testing.assert_allclose(zc.grad.float().cpu().numpy(), dz_ref.numpy(), rtol=1e-2, atol=1e-2)
+
+
+def test_large_properties_and_determinism():
+    """Config-3-like size-independent properties: z_q rows ARE codebook rows, histogram sums to B,
+    idempotence (quantising z_q returns the same codes), bitwise run-to-run reproducibility."""
+    B, n_e, D = 1 << 18, 512, 256
+    torch.manual_seed(0)
+    W = torch.randn(n_e, D)
+    vq = _mod(n_e, D, 0.25, W.numpy(), one_hot=False)
+    for dt in (torch.float32, torch.bfloat16):
+        z = torch.randn(B, D, device="cuda").to(dt).requires_grad_(True)
+        l1, q1, p1, _, i1 = vq(z)
+        l2, q2, p2, _, i2 = vq(z)
+        assert torch.equal(i1, i2) and torch.equal(q1, q2) and torch.equal(l1, l2) and torch.equal(p1, p2)
+        assert torch.equal(q1.detach(), vq.embedding.weight[i1[:, 0]].to(dt))
+        assert int(torch.bincount(i1[:, 0], minlength=n_e).sum()) == B
+        _, _, _, _, i3 = vq(q1.detach())
+        if dt == torch.float32:
+            assert torch.equal(i3, i1)
+        (l1 + q1.float().sum()).backward()
+        g1 = vq.embedding.weight.grad.clone(); vq.embedding.weight.grad = None
+        dz1 = z.grad.clone(); z.grad = None
+        l1b, q1b, _, _, _ = vq(z)
+        (l1b + q1b.float().sum()).backward()
+        assert torch.equal(g1, vq.embedding.weight.grad) and torch.equal(dz1, z.grad)
+        vq.embedding.weight.grad = None
+        # codebook gradient vs a dense torch restatement
+        onehot = torch.zeros(B, n_e, device="cuda").scatter_(1, i1, 1.0)
+        cnt = onehot.sum(0)
+        ref = 0.25 * 2.0 / (B * D) * (cnt[:, None] * vq.embedding.weight.detach() - onehot.t() @ z.detach().float())
+        torch.testing.assert_close(g1, ref, rtol=1e-3 if dt == torch.bfloat16 else 1e-4, atol=1e-7)
+
+
+def test_errors_are_loud():
+    from causal_eeg_vae_amd import VectorQuantizer, CeegError
+    vq = VectorQuantizer(16, 8, 0.25)
+    with pytest.raises(CeegError):
+        vq(torch.randn(4, 8))  # CPU tensor: no fallback
+    vq = VectorQuantizer(16, 300, 0.25).cuda()
+    with pytest.raises(CeegError):
+        vq(torch.randn(4, 300, device="cuda"))  # e_dim > 256 unsupported
+    with pytest.raises(ValueError):
+        VectorQuantizer(16, 8, 0.25).cuda()(torch.randn(4, 9, device="cuda"))
