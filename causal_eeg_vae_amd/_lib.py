@@ -89,3 +89,36 @@ def require_cuda(*tensors):
         if t is not None and not t.is_cuda:
             raise CeegError("causal_eeg_vae_amd runs on MI355X (ROCm) tensors only; got a CPU tensor. "
                             "There is no CPU fallback in the product path (the CPU oracle lives under oracle/ for tests).")
+
+
+# ---------------------------------------------------------------------------------------------------
+# Optional per-call HIP-event timing (bench.py): PROFILE = {} switches it on; entries are
+# name -> [(start_event, end_event), ...] recorded on the stream the kernels are launched on.
+PROFILE = None
+
+
+class timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e.record()
+            PROFILE.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def profile_summary():
+    """name -> (launches, mean ms).  Call after torch.cuda.synchronize()."""
+    out = {}
+    for k, evs in (PROFILE or {}).items():
+        ms = [s.elapsed_time(e) for s, e in evs]
+        out[k] = (len(ms), sum(ms) / max(len(ms), 1))
+    return out

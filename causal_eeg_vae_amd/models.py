@@ -102,9 +102,10 @@ def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, a
     if out is None:
         out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
     ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
-    _lib.check(L.ceeg_spmm_csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
-                               n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
-                               ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr")
+    with _lib.timed(f"spmm_F{F}"):
+        _lib.check(L.ceeg_spmm_csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
+                                   n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
+                                   ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr")
     return out
 
 

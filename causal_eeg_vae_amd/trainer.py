@@ -1,0 +1,44 @@
+"""Training step of the VGAE + VQ model: the host loop of /root/reference/scripts/run.py:54-98 restated
+(Adam lr 1e-3, zero_grad -> forward -> sum of losses -> backward -> step), plus data-parallel gradient
+averaging over RCCL (one flat all-reduce per step; one process per GPU, graph shards never exchange data)."""
+import torch
+import torch.distributed as dist
+
+
+def allreduce_grads_(params, world_size):
+    """Average gradients across ranks with ONE flat all-reduce (sum) followed by 1/world_size."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads or world_size <= 1:
+        return
+    flat = torch._utils._flatten_dense_tensors(grads)
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(world_size)
+    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+        g.copy_(f)
+
+
+def broadcast_params_(module, src=0):
+    for p in module.parameters():
+        dist.broadcast(p.data, src=src)
+    for b in module.buffers():
+        dist.broadcast(b.data, src=src)
+
+
+class Trainer:
+    def __init__(self, model, lr=1e-3, world_size=1):
+        self.model = model
+        self.world_size = int(world_size)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.opt = torch.optim.Adam(self.params, lr=lr)  # scripts/run.py:56
+        self.step_idx = 0
+        if self.world_size > 1:
+            broadcast_params_(model)
+
+    def step(self, x, graph, eps=None):
+        self.opt.zero_grad(set_to_none=True)                 # scripts/run.py:87
+        loss, aux = self.model(x, graph, step=self.step_idx, eps=eps)  # scripts/run.py:89-95
+        loss.backward()                                      # scripts/run.py:96
+        allreduce_grads_(self.params, self.world_size)
+        self.opt.step()                                      # scripts/run.py:97
+        self.step_idx += 1
+        return loss.detach(), aux                            # no host sync here (run.py:98 syncs every step)
