@@ -141,29 +141,35 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
         my_c = col[base + lane];
         my_valid = (my_c != (int)sr && !sorted_has(col, s_lo, s_hi, my_c)) ? 1 : 0;
       }
-#pragma unroll 4
-      for (int i = 0; i < 64 / G; ++i) {
-        if (i * G >= n) break;  // wave-uniform
-        const int j = i * G + sub;
-        const int c = __shfl(my_c, j, 64);
-        const int valid = __shfl(my_valid, j, 64);
-        const bool ok = j < n;
-        float dp = 0.f, dn = 0.f;
-        if (ok && fl_ok) {
-          const float4 x = *reinterpret_cast<const float4*>(z + (int64_t)c * ldz + 4 * fl);
-          dp = dot4(x, zr);
-          dn = dot4(x, zs);
+      const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
+      for (int i0 = 0; i0 < ns; i0 += 4) {
+        // up to 4 gathers in flight, then the 4 pairs of dot products
+        float4 x[4];
+        int cv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int j = (i0 + k) * G + sub;
+          const int c = __shfl(my_c, j & 63, 64);
+          cv[k] = __shfl(my_valid, j & 63, 64);
+          x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i0 + k < ns && j < n && fl_ok) x[k] = *reinterpret_cast<const float4*>(z + (int64_t)c * ldz + 4 * fl);
         }
-        dp = group_sum<LPR>(dp);
-        dn = group_sum<LPR>(dn);
-        if (ok && fl == 0) {
-          float tp, cp, tn, cn;
-          dec_pos(dp, tp, cp);
-          dec_neg(dn, tn, cn);
-          coef_pos[base + j] = cp;
-          coef_neg[base + j] = valid ? cn : 0.f;
-          s_pos += tp;
-          if (valid) { s_neg += tn; s_cnt += 1.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (i0 + k >= ns) break;  // wave-uniform
+          const int j = (i0 + k) * G + sub;
+          const bool ok = j < n;
+          const float dp = group_sum<LPR>(dot4(x[k], zr));
+          const float dn = group_sum<LPR>(dot4(x[k], zs));
+          if (ok && fl == 0) {
+            float tp, cp, tn, cn;
+            dec_pos(dp, tp, cp);
+            dec_neg(dn, tn, cn);
+            coef_pos[base + j] = cp;
+            coef_neg[base + j] = cv[k] ? cn : 0.f;
+            s_pos += tp;
+            if (cv[k]) { s_neg += tn; s_cnt += 1.0f; }
+          }
         }
       }
     }

@@ -22,44 +22,80 @@ namespace {
 
 constexpr int SPMM_CHUNK = 256;  // nonzeros per long-row piece
 constexpr int SPMM_WAVES = 4;    // rows (waves) per workgroup
+constexpr int SPMM_BLOCKS_PER_XCD = 256;  // persistent grid: 32 CUs x 8 workgroups per XCD
+constexpr int SPMM_GRAB = 4;     // consecutive rows per queue draw (one per wave: keeps the XCD window of live rows tight)
+constexpr size_t SPMM_QUEUE_BYTES = 1024;  // 8 counters on 128-byte lines of their own, one memset per pass
 
+// K consecutive steps of a batch: step i covers entries j = i*G + g of the batch (g = lane group).
+// All K gathers are issued before the first FMA (K x 1 KiB per wave in flight), the FMAs then run in
+// ascending entry order, so the summation order does not depend on K.
+template <int LPR, int K>
+__device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n, int sub, const float* __restrict__ X,
+                                             int64_t ldx, int foff, bool fl_ok, float4& acc) {
+  constexpr int G = 64 / LPR;
+  float4 x[K];
+  float v[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = i0 + k;
+    int c;
+    bool ld = fl_ok;
+    if constexpr (G == 1) {
+      c = __builtin_amdgcn_readlane(my_c, i);
+      v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), i));
+    } else {
+      const int j = i * G + sub;
+      c = __shfl(my_c, j, 64);
+      v[k] = __shfl(my_v, j, 64);
+      ld = ld && j < n;
+    }
+    x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ld) x[k] = *reinterpret_cast<const float4*>(X + (int64_t)c * ldx + foff);
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if constexpr (G > 1) {
+      if (!(i0 + k < (n + G - 1) / G && (i0 + k) * G + sub < n)) continue;  // lanes past the batch end add nothing
+    }
+    acc.x = __fmaf_rn(v[k], x[k].x, acc.x);
+    acc.y = __fmaf_rn(v[k], x[k].y, acc.y);
+    acc.z = __fmaf_rn(v[k], x[k].z, acc.z);
+    acc.w = __fmaf_rn(v[k], x[k].w, acc.w);
+  }
+}
+
+// one lane-parallel load of up to 64 (column, value) pairs starting at position `base`
+__device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                           const int32_t* __restrict__ vperm, int base, int p_hi, int lane, const CeegSpmmEx& ex,
+                                           int& my_c, float& my_v) {
+  my_c = 0;
+  my_v = 0.f;
+  if (base + lane < p_hi) {
+    my_c = col[base + lane];
+    if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)(((uint64_t)ex.col_a * (uint64_t)my_c + (uint64_t)ex.col_b) % (uint64_t)ex.mod);
+    my_v = vperm ? val[vperm[base + lane]] : val[base + lane];
+  }
+}
+
+// sum over positions [p_lo, p_hi); (my_c, my_v) hold the already-loaded first batch (positions p_lo .. p_lo+63)
 template <int LPR>
-__device__ __forceinline__ float4 seg_sum(const int32_t* __restrict__ col, const float* __restrict__ val,
-                                          const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx,
-                                          int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex) {
+__device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                              const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx,
+                                              int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex,
+                                              int my_c, float my_v) {
   constexpr int G = 64 / LPR;
   const int sub = lane / LPR;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int base = p_lo; base < p_hi; base += 64) {
     const int n = p_hi - base < 64 ? p_hi - base : 64;
-    int my_c = 0;
-    float my_v = 0.f;
-    if (lane < n) {
-      my_c = col[base + lane];
-      if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)(((uint64_t)ex.col_a * (uint64_t)my_c + (uint64_t)ex.col_b) % (uint64_t)ex.mod);
-      my_v = vperm ? val[vperm[base + lane]] : val[base + lane];
-    }
-#pragma unroll 8
-    for (int i = 0; i < 64 / G; ++i) {
-      if (i * G >= n) break;  // wave-uniform
-      int c;
-      float v;
-      if constexpr (G == 1) {
-        c = __builtin_amdgcn_readlane(my_c, i);
-        v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), i));
-      } else {
-        const int j = i * G + sub;
-        c = __shfl(my_c, j, 64);
-        v = __shfl(my_v, j, 64);  // 0 for j >= n: contributes exactly nothing below
-      }
-      if (fl_ok && (G == 1 || i * G + sub < n)) {
-        const float4 x = *reinterpret_cast<const float4*>(X + (int64_t)c * ldx + foff);
-        acc.x = __fmaf_rn(v, x.x, acc.x);
-        acc.y = __fmaf_rn(v, x.y, acc.y);
-        acc.z = __fmaf_rn(v, x.z, acc.z);
-        acc.w = __fmaf_rn(v, x.w, acc.w);
-      }
-    }
+    if (base != p_lo) load_batch(col, val, vperm, base, p_hi, lane, ex, my_c, my_v);
+    const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
+    int i0 = 0;
+    for (; i0 + 8 <= ns; i0 += 8) gather_steps<LPR, 8>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc);
+    const int rem = ns - i0;
+    if (rem & 4) { gather_steps<LPR, 4>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 4; }
+    if (rem & 2) { gather_steps<LPR, 2>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 2; }
+    if (rem & 1) { gather_steps<LPR, 1>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); }
   }
   if constexpr (G > 1) {
 #pragma unroll
@@ -71,6 +107,16 @@ __device__ __forceinline__ float4 seg_sum(const int32_t* __restrict__ col, const
     }
   }
   return acc;
+}
+
+template <int LPR>
+__device__ __forceinline__ float4 seg_sum(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                          const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx,
+                                          int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex) {
+  int my_c;
+  float my_v;
+  load_batch(col, val, vperm, p_lo, p_hi, lane, ex, my_c, my_v);
+  return seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, my_c, my_v);
 }
 
 __device__ __forceinline__ int row_of(const int32_t* __restrict__ rowptr, int64_t N, int p) {
@@ -111,57 +157,106 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_kernel(
   }
 }
 
+// first row r in [0, N] with rowptr[r] >= target
+__device__ __forceinline__ int64_t row_lower_bound(const int32_t* __restrict__ rowptr, int64_t N, int64_t target) {
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// Persistent row kernel with one in-order work queue per XCD.
+//  * XCD-aware AND nonzero-balanced: the workgroups sharing blockIdx%8 (= one XCD, one L2) own one
+//    CONTIGUOUS range of rows holding ~1/8 of the nonzeros (hub rows of the transposed event graph sit at
+//    low ids: equal row counts would leave XCD 0 with 3x the work).
+//  * Inside the range, workgroups draw the next SPMM_GRAB consecutive rows from the XCD's counter
+//    (one returning atomic per workgroup per grab), so the XCD sweeps its range strictly in order with a
+//    tight window of live rows: time-local events re-use their gathered neighbours from that L2, and
+//    heavy rows cannot unbalance the waves.  Which wave computes a row never changes its value.
+//  Every workgroup leaves when its draw passes the end of the range (the counter only grows).
 template <int LPR>
 __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
     const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
     const float* __restrict__ bias, int relu, int accumulate, float* __restrict__ out, int64_t ldo,
-    const float* __restrict__ partial, int64_t nblk, CeegSpmmEx ex) {
-  // XCD-aware remap: the blocks sharing blockIdx%8 walk one contiguous slab of rows
-  const int64_t per = (nblk + 7) / 8;
-  const int64_t vb = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-  if (vb >= nblk) return;
+    const float* __restrict__ partial, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed before the launch */, CeegSpmmEx ex) {
+  __shared__ unsigned int s_draw[2];
+  constexpr int RPW = SPMM_GRAB / SPMM_WAVES;  // consecutive rows per wave per draw
   const int lane = threadIdx.x & 63;
-  const int64_t r = vb * SPMM_WAVES + (threadIdx.x >> 6);
-  if (r >= N) return;
+  const int xcd = blockIdx.x & 7;
+  const int64_t nnz = rowptr[N];
+  const int64_t r_begin = xcd == 0 ? 0 : row_lower_bound(rowptr, N, nnz * xcd / 8);
+  const int64_t r_end = xcd == 7 ? N : row_lower_bound(rowptr, N, nnz * (xcd + 1) / 8);
   const int fl = lane % LPR;
   const int foff = fbase + 4 * fl;
   const bool fl_ok = foff < F;
-  const int p_lo = rowptr[r], p_hi = rowptr[r + 1];
-  float4 acc;
-  if (p_hi - p_lo <= SPMM_CHUNK) {
-    acc = seg_sum<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex);
-  } else {
-    acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
-    if (lane < LPR && fl_ok) {
-      for (int c = c_lo; c <= c_hi; ++c) {  // pieces in ascending position order
-        const int slot = (c == c_lo && p_lo != c * SPMM_CHUNK) ? 1 : 0;
-        const float4 a = *reinterpret_cast<const float4*>(partial + ((size_t)c * 2 + slot) * (4 * LPR) + 4 * fl);
-        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+  unsigned int draw = 0;
+  if (threadIdx.x == 0) draw = atomicAdd(&queue[xcd * 32], (unsigned)SPMM_GRAB);
+  for (int it = 0;; ++it) {
+    if (threadIdx.x == 0) s_draw[it & 1] = draw;
+    __syncthreads();  // slot it&1 is rewritten two iterations later, i.e. after every wave passed the next barrier
+    const int64_t base = r_begin + s_draw[it & 1];
+    if (base >= r_end) break;
+    if (threadIdx.x == 0) draw = atomicAdd(&queue[xcd * 32], (unsigned)SPMM_GRAB);  // next draw, consumed next iteration
+    const int64_t r0 = base + (threadIdx.x >> 6) * RPW;
+    if (r0 >= r_end) continue;
+    // row pointers of the wave's RPW rows with one load; first (col,val) batch of every row up front, so the
+    // rowptr -> col/val -> gather latency chain is paid once per draw, not once per row
+    int rp = 0;
+    if (lane <= RPW) rp = rowptr[(r0 + lane <= N) ? r0 + lane : N];
+    int pp[RPW + 1];
+#pragma unroll
+    for (int k = 0; k <= RPW; ++k) pp[k] = __builtin_amdgcn_readlane(rp, k);
+    int bc[RPW];
+    float bv[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      bc[k] = 0; bv[k] = 0.f;
+      if (r0 + k < r_end && pp[k + 1] - pp[k] <= SPMM_CHUNK) load_batch(col, val, vperm, pp[k], pp[k + 1], lane, ex, bc[k], bv[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int64_t r = r0 + k;
+      if (r >= r_end) break;
+      const int p_lo = pp[k], p_hi = pp[k + 1];
+      float4 acc;
+      if (p_hi - p_lo <= SPMM_CHUNK) {
+        acc = seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc[k], bv[k]);
+      } else {
+        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
+        if (lane < LPR && fl_ok) {
+          for (int c = c_lo; c <= c_hi; ++c) {  // pieces in ascending position order
+            const int slot = (c == c_lo && p_lo != c * SPMM_CHUNK) ? 1 : 0;
+            const float4 a = *reinterpret_cast<const float4*>(partial + ((size_t)c * 2 + slot) * (4 * LPR) + 4 * fl);
+            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+          }
+        }
+      }
+      if (lane < LPR && fl_ok) {
+        if (ex.scale) {
+          const float sc = ex.scale[0];
+          acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
+        }
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + foff);
+          acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
+        }
+        int64_t ro = r;
+        if (ex.row_a != 1 || ex.row_b != 0) ro = (int64_t)(((uint64_t)ex.row_a * (uint64_t)r + (uint64_t)ex.row_b) % (uint64_t)ex.mod);
+        float* o = out + ro * ldo + foff;
+        if (accumulate) {
+          const float4 t = *reinterpret_cast<const float4*>(o);
+          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        }
+        if (relu) {
+          acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(o) = acc;
       }
     }
-  }
-  if (lane < LPR && fl_ok) {
-    if (ex.scale) {
-      const float sc = ex.scale[0];
-      acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
-    }
-    if (bias) {
-      const float4 b = *reinterpret_cast<const float4*>(bias + foff);
-      acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
-    }
-    int64_t ro = r;
-    if (ex.row_a != 1 || ex.row_b != 0) ro = (int64_t)(((uint64_t)ex.row_a * (uint64_t)r + (uint64_t)ex.row_b) % (uint64_t)ex.mod);
-    float* o = out + ro * ldo + foff;
-    if (accumulate) {
-      const float4 t = *reinterpret_cast<const float4*>(o);
-      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
-    }
-    if (relu) {
-      acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
-    }
-    *reinterpret_cast<float4*>(o) = acc;
   }
 }
 
@@ -175,17 +270,18 @@ int lpr_for(int F) {
 template <int LPR>
 int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm, const float* X,
                 int64_t ldx, int64_t N, int64_t nnz, int F, int fbase, const float* bias, int relu, int accumulate,
-                float* out, int64_t ldo, float* partial, hipStream_t st, const CeegSpmmEx& ex) {
+                float* out, int64_t ldo, float* partial, unsigned int* queue, hipStream_t st, const CeegSpmmEx& ex) {
   const int64_t nchunk = (nnz + SPMM_CHUNK - 1) / SPMM_CHUNK;
   if (nchunk > 0) {
     hipLaunchKernelGGL(spmm_long_kernel<LPR>, dim3((unsigned)((nchunk + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64), 0, st,
                        rowptr, col, val, vperm, X, ldx, N, F, fbase, partial, ex);
     CEEG_CHECK_LAUNCH();
   }
-  const int64_t nblk = (N + SPMM_WAVES - 1) / SPMM_WAVES;
-  const int64_t grid = (nblk + 7) / 8 * 8;
-  hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)grid), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx, N, F,
-                     fbase, bias, relu, accumulate, out, ldo, partial, nblk, ex);
+  if (hipMemsetAsync(queue, 0, SPMM_QUEUE_BYTES, st) != hipSuccess) return CEEG_ELAUNCH;
+  int64_t per_xcd = (N + 8 * SPMM_GRAB - 1) / (8 * SPMM_GRAB);  // blocks per XCD: enough for one draw each ...
+  if (per_xcd > SPMM_BLOCKS_PER_XCD) per_xcd = SPMM_BLOCKS_PER_XCD;  // ... capped at 8 resident blocks on each of 32 CUs
+  hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)(8 * per_xcd)), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx,
+                     N, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, ex);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
@@ -197,7 +293,7 @@ extern "C" size_t ceeg_spmm_ws_bytes(int64_t N, int64_t nnz, int F) {
   if (nnz < 0 || F <= 0) return 0;
   const int lpr = lpr_for(F);
   const int64_t nchunk = (nnz + SPMM_CHUNK - 1) / SPMM_CHUNK;
-  return ceeg_ws_part((size_t)(nchunk + 1) * 2 * 4 * lpr, 4);
+  return SPMM_QUEUE_BYTES + ceeg_ws_part((size_t)(nchunk + 1) * 2 * 4 * lpr, 4);
 }
 
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
@@ -209,13 +305,14 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
   if (!ceeg_aligned(X, 16) || !ceeg_aligned(out, 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
   if (nnz >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ws_bytes < ceeg_spmm_ws_bytes(N, nnz, F) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
-  float* partial = static_cast<float*>(ws);
+  unsigned int* queue = static_cast<unsigned int*>(ws);
+  float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + SPMM_QUEUE_BYTES);
   const int lpr = lpr_for(F);
   int rc = CEEG_OK;
   for (int fbase = 0; fbase < F && rc == CEEG_OK; fbase += 4 * lpr) {
 #define CEEG_SPMM_CASE(L)                                                                                                       \
   case L:                                                                                                                       \
-    rc = launch_pass<L>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, st, ex); \
+    rc = launch_pass<L>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, st, ex); \
     break;
     switch (lpr) {
       CEEG_SPMM_CASE(1)
