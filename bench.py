@@ -158,7 +158,7 @@ def main():
         nnz = graph.gcn.nnz
         # compulsory bytes of one SpMM pass of width F
         spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * F * 4
-        launches, spmm_ms = prof.get(f"spmm_F{F}", (0, float("nan")))
+        launches, spmm_ms = prof.get(f"spmm_F{F}", (0, float("nan")))  # layer-2 aggregation (fwd) and its transposed pass (bwd)
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
         line = {"metric": "VGAE train edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",

@@ -16,6 +16,7 @@
 //     (hub rows of the transposed event graph reach 1e4-1e5 entries; one wave per hub would serialise.)
 // XCD-aware: workgroups with equal blockIdx%8 (= same XCD, same L2) get one contiguous range of rows, so
 // time-local rows of the event DAG share their gathered neighbours in one L2.
+#include <stdlib.h>
 #include "ceeg_internal.h"
 
 namespace {
@@ -279,7 +280,8 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
   }
   if (hipMemsetAsync(queue, 0, SPMM_QUEUE_BYTES, st) != hipSuccess) return CEEG_ELAUNCH;
   int64_t per_xcd = (N + 8 * SPMM_GRAB - 1) / (8 * SPMM_GRAB);  // blocks per XCD: enough for one draw each ...
-  if (per_xcd > SPMM_BLOCKS_PER_XCD) per_xcd = SPMM_BLOCKS_PER_XCD;  // ... capped at 8 resident blocks on each of 32 CUs
+  static const int bpx_cap = getenv("CEEG_SPMM_BPX") ? atoi(getenv("CEEG_SPMM_BPX")) : SPMM_BLOCKS_PER_XCD;  // tuning knob
+  if (per_xcd > bpx_cap) per_xcd = bpx_cap;  // ... capped at 8 resident blocks on each of 32 CUs
   hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)(8 * per_xcd)), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx,
                      N, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, ex);
   CEEG_CHECK_LAUNCH();
