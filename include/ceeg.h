@@ -61,8 +61,8 @@ int ceeg_check_device(void);
  *                  dropped); no reference counterpart.
  *
  * z [B,D], W [n_e,D] fp32, z_q [B,D] (dtype), idx [B] int64, loss/perplexity: 1 float each (device),
- * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 65536, B >= 0.
- * B == 0 writes loss = NaN-free zeros? No: B == 0 is CEEG_EINVAL (the reference divides by zero).
+ * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 16384, B >= 1
+ * (B == 0 is CEEG_EINVAL: the reference divides by zero there).
  * ----------------------------------------------------------------------------------------------*/
 size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype);
 int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
