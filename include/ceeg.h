@@ -86,9 +86,10 @@ int ceeg_vq_backward(const void* z, const float* W, const int64_t* idx, const vo
  * ceeg_csr_build: edge list (src[e] -> dst[e], int64, PyG edge_index rows 0 and 1) -> CSR grouped by
  *   dst, entries ordered by (dst, src, original edge id): THE canonical edge order.  With
  *   self_loops=1 it applies add_remaining_self_loops: every existing self-loop is dropped and exactly
- *   one (i,i) entry per node is added (perm = -1-i ... see below).  Outputs:
- *     rowptr [N+1] int32, col [nnz] int32 (source node), perm [nnz] int32 (original edge id, or -1 for
- *     an added self-loop), nnz_out: 1 int64 on the DEVICE.  nnz upper bound = E + (self_loops ? N : 0):
+ *   one (i,i) entry per node is added (its perm is the LAST dropped self-loop's edge id, whose weight
+ *   PyG keeps, or -1 when the node had none).  Outputs:
+ *     rowptr [N+1] int32, col [nnz] int32 (source node), perm [nnz] int32 (original edge id; see above for
+ *     self-loops), nnz_out: 1 int64 on the DEVICE.  nnz upper bound = E + (self_loops ? N : 0):
  *     col/perm must have that capacity.
  * ceeg_csr_transpose: CSR (rows=dst) -> CSR of the transpose (rows=src), entries ordered by
  *   (src, dst, position); tperm[q] = position p in the input CSR, so values permute as val_t[q]=val[tperm[q]].
