@@ -25,7 +25,8 @@ constexpr int SPMM_CHUNK = 256;  // nonzeros per long-row piece
 constexpr int SPMM_WAVES = 4;    // rows (waves) per workgroup
 constexpr int SPMM_BLOCKS_PER_XCD = 256;  // persistent grid: 32 CUs x 8 workgroups per XCD
 constexpr int SPMM_GRAB = 4;     // consecutive rows per queue draw (one per wave: keeps the XCD window of live rows tight)
-constexpr size_t SPMM_QUEUE_BYTES = 1024;  // 8 counters on 128-byte lines of their own, one memset per pass
+constexpr int SPMM_SUBQ = 4;      // interleaved sub-queues per XCD (spreads the returning atomics over 4 words)
+constexpr size_t SPMM_QUEUE_BYTES = 8 * SPMM_SUBQ * 128;  // 8 counters on 128-byte lines of their own, one memset per pass
 
 // K consecutive steps of a batch: step i covers entries j = i*G + g of the batch (g = lane group).
 // All K gathers are issued before the first FMA (K x 1 KiB per wave in flight), the FMAs then run in
@@ -183,9 +184,10 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
     const float* __restrict__ bias, int relu, int accumulate, float* __restrict__ out, int64_t ldo,
     const float* __restrict__ partial, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed before the launch */, CeegSpmmEx ex) {
+  static_assert(SPMM_GRAB == SPMM_WAVES, "one row per wave per draw");
   __shared__ unsigned int s_draw[2];
-  constexpr int RPW = SPMM_GRAB / SPMM_WAVES;  // consecutive rows per wave per draw
   const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
   const int xcd = blockIdx.x & 7;
   const int64_t nnz = rowptr[N];
   const int64_t r_begin = xcd == 0 ? 0 : row_lower_bound(rowptr, N, nnz * xcd / 8);
@@ -193,38 +195,51 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
   const int fl = lane % LPR;
   const int foff = fbase + 4 * fl;
   const bool fl_ok = foff < F;
+  const int subq = (blockIdx.x >> 3) % SPMM_SUBQ;
+  unsigned int* q = queue + (xcd * SPMM_SUBQ + subq) * 32;
+  // draw value d (a multiple of GRAB) of sub-queue s -> row set (d/GRAB)*SUBQ + s: the sub-queues interleave
+  auto set_base = [&](unsigned d) -> int64_t { return r_begin + ((int64_t)(d / SPMM_GRAB) * SPMM_SUBQ + subq) * SPMM_GRAB; };
+
+  // Software pipeline over the workgroup's draws (one row per wave per draw):
+  //   iteration `it` GATHERS row(it) while the (col,val) batch of row(it+1), the row pointers of row(it+2)
+  //   and the queue draw for it+2 are in flight - each dependent load gets a whole iteration to land, so a
+  //   row costs one gather latency instead of the rowptr -> col/val -> gather chain.
+  // Only metadata runs ahead; the rows being gathered stay one consecutive band per XCD.
+  auto row_ptrs = [&](int64_t base) -> int {  // lanes 0,1: rowptr[r], rowptr[r+1] (0,0 past the range)
+    const int64_t r = base + wave;
+    int v = 0;
+    if (lane < 2 && r < r_end) v = rowptr[r + lane];
+    return v;
+  };
+  if (threadIdx.x == 0) {
+    const unsigned d0 = atomicAdd(q, (unsigned)SPMM_GRAB);
+    const unsigned d1 = atomicAdd(q, (unsigned)SPMM_GRAB);
+    s_draw[0] = d0;
+    s_draw[1] = d1;
+  }
+  __syncthreads();
+  int64_t base_cur = set_base(s_draw[0]), base_nxt = set_base(s_draw[1]);
+  __syncthreads();
+  int rp = row_ptrs(base_cur);
+  int p_lo = __builtin_amdgcn_readlane(rp, 0), p_hi = __builtin_amdgcn_readlane(rp, 1);
+  int bc = 0;
+  float bv = 0.f;
+  if (p_hi - p_lo <= SPMM_CHUNK) load_batch(col, val, vperm, p_lo, p_hi, lane, ex, bc, bv);
+  int rp_n = row_ptrs(base_nxt);
   unsigned int draw = 0;
-  if (threadIdx.x == 0) draw = atomicAdd(&queue[xcd * 32], (unsigned)SPMM_GRAB);
-  for (int it = 0;; ++it) {
-    if (threadIdx.x == 0) s_draw[it & 1] = draw;
-    __syncthreads();  // slot it&1 is rewritten two iterations later, i.e. after every wave passed the next barrier
-    const int64_t base = r_begin + s_draw[it & 1];
-    if (base >= r_end) break;
-    if (threadIdx.x == 0) draw = atomicAdd(&queue[xcd * 32], (unsigned)SPMM_GRAB);  // next draw, consumed next iteration
-    const int64_t r0 = base + (threadIdx.x >> 6) * RPW;
-    if (r0 >= r_end) continue;
-    // row pointers of the wave's RPW rows with one load; first (col,val) batch of every row up front, so the
-    // rowptr -> col/val -> gather latency chain is paid once per draw, not once per row
-    int rp = 0;
-    if (lane <= RPW) rp = rowptr[(r0 + lane <= N) ? r0 + lane : N];
-    int pp[RPW + 1];
-#pragma unroll
-    for (int k = 0; k <= RPW; ++k) pp[k] = __builtin_amdgcn_readlane(rp, k);
-    int bc[RPW];
-    float bv[RPW];
-#pragma unroll
-    for (int k = 0; k < RPW; ++k) {
-      bc[k] = 0; bv[k] = 0.f;
-      if (r0 + k < r_end && pp[k + 1] - pp[k] <= SPMM_CHUNK) load_batch(col, val, vperm, pp[k], pp[k + 1], lane, ex, bc[k], bv[k]);
-    }
-#pragma unroll
-    for (int k = 0; k < RPW; ++k) {
-      const int64_t r = r0 + k;
-      if (r >= r_end) break;
-      const int p_lo = pp[k], p_hi = pp[k + 1];
+  for (int it = 0; base_cur < r_end; ++it) {
+    if (threadIdx.x == 0) draw = atomicAdd(q, (unsigned)SPMM_GRAB);  // draw it+2
+    // (col,val) batch of the next row
+    const int p_lo_n = __builtin_amdgcn_readlane(rp_n, 0), p_hi_n = __builtin_amdgcn_readlane(rp_n, 1);
+    int bc_n = 0;
+    float bv_n = 0.f;
+    if (p_hi_n - p_lo_n <= SPMM_CHUNK) load_batch(col, val, vperm, p_lo_n, p_hi_n, lane, ex, bc_n, bv_n);
+    // gather + store the current row
+    const int64_t r = base_cur + wave;
+    if (r < r_end) {
       float4 acc;
       if (p_hi - p_lo <= SPMM_CHUNK) {
-        acc = seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc[k], bv[k]);
+        acc = seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
       } else {
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
@@ -258,6 +273,14 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         *reinterpret_cast<float4*>(o) = acc;
       }
     }
+    // publish draw it+2 (slot it&1 was last read two barriers ago), start the row-pointer load of row(it+2)
+    if (threadIdx.x == 0) s_draw[it & 1] = draw;
+    __syncthreads();
+    const int64_t base_nn = set_base(s_draw[it & 1]);
+    base_cur = base_nxt;
+    base_nxt = base_nn;
+    p_lo = p_lo_n; p_hi = p_hi_n; bc = bc_n; bv = bv_n;
+    rp_n = row_ptrs(base_nn);
   }
 }
 
