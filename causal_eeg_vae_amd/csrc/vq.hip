@@ -34,10 +34,15 @@ __host__ __device__ constexpr int vq_min(int a, int b) { return a < b ? a : b; }
 
 // ------------------------------------------------------------------------------------------ prep
 // ee / image.  One thread per code computes the norm chain; all threads then write image elements.
+// Image layout (what the main kernel copies verbatim into LDS, one chunk of CT codes at a time):
+//   chunk ch at byte offset ch*CHB, CHB = CT*DP*elt + CT*4:
+//     [CT rows x DP elements, 16-byte pieces XOR-swizzled inside each row][CT floats: ee (fp32) or -ee/2 (bf16)]
 template <bool BF16>
-__global__ void vq_prep_kernel(const float* __restrict__ W, int n_e, int D, int n_ep, int DP,
-                               float* __restrict__ ee, void* __restrict__ img) {
+__global__ void vq_prep_kernel(const float* __restrict__ W, int n_e, int D, int n_ep, int DP, int CT,
+                               float* __restrict__ ee, char* __restrict__ img) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t elt = BF16 ? 2 : 4;
+  const size_t chb = (size_t)CT * DP * elt + (size_t)CT * 4;
   if (tid < n_ep) {
     const int c = (int)tid;
     float e;
@@ -53,22 +58,41 @@ __global__ void vq_prep_kernel(const float* __restrict__ W, int n_e, int D, int 
       e = BF16 ? -INFINITY : INFINITY;  // padded codes can never win
     }
     ee[c] = e;
+    *reinterpret_cast<float*>(img + (size_t)(c / CT) * chb + (size_t)CT * DP * elt + (size_t)(c % CT) * 4) = e;
   }
   const int64_t total = (int64_t)n_ep * DP;
   for (int64_t i = tid; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(i / DP), k = (int)(i % DP);
     const float w = (c < n_e && k < D) ? W[(size_t)c * D + k] : 0.f;
+    char* rows = img + (size_t)(c / CT) * chb;
+    const int cl = c % CT;
     if (BF16) {
       const int cpr = DP / 8;                       // 16-byte chunks per row
       const int swz = c & (vq_min(16, cpr) - 1);
       const int chunk = k >> 3;
-      reinterpret_cast<unsigned short*>(img)[(size_t)c * DP + ((chunk ^ swz) << 3) + (k & 7)] = ceeg_f32_to_bf16(w);
+      reinterpret_cast<unsigned short*>(rows)[(size_t)cl * DP + ((chunk ^ swz) << 3) + (k & 7)] = ceeg_f32_to_bf16(w);
     } else {
       const int q = k & 3, s = k >> 2;              // de-interleave by k mod 4 (the MFMA's k index)
       const int cpq = DP / 16;                      // 16-byte chunks per quarter row
       const int swz = c & (vq_min(16, cpq) - 1);
       const int chunk = s >> 2, e = s & 3;
-      reinterpret_cast<float*>(img)[(size_t)c * DP + q * (DP / 4) + ((chunk ^ swz) << 2) + e] = w;
+      reinterpret_cast<float*>(rows)[(size_t)cl * DP + q * (DP / 4) + ((chunk ^ swz) << 2) + e] = w;
+    }
+  }
+}
+
+// Asynchronous global -> LDS copy of one image chunk (PIECES x 16 bytes) with global_load_lds_dwordx4: no
+// VGPR staging, the data lands while the MFMAs of the current chunk run.  The LDS address of a piece is
+// (wave-uniform base) + lane*16, so the base passed is lane 0's; tail pieces go to lanes 0..k of one wave.
+template <int PIECES>
+__device__ __forceinline__ void vq_stage_chunk(const char* __restrict__ gsrc, char* ldst) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i0 = 0; i0 < PIECES; i0 += VQ_THREADS) {
+    const int i = i0 + (int)threadIdx.x;
+    if (i < PIECES) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsrc + (size_t)i * 16),
+                                       (__attribute__((address_space(3))) void*)(ldst + (size_t)(i - lane) * 16), 16, 0, 0);
     }
   }
 }
@@ -108,9 +132,11 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
   constexpr int SWZ_MASK = vq_min(16, CPQ) - 1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* lds_w = reinterpret_cast<float*>(smem);                 // [CT][DP]
-  int* lds_idx = reinterpret_cast<int*>(smem + CT * DP * 4);     // [BM]
-  float* lds_red = reinterpret_cast<float*>(smem + CT * DP * 4 + BM * 4);  // [VQ_WAVES]
+  constexpr int CHB = CT * DP * 4 + CT * 4;                      // one image chunk: rows + ee
+  int* lds_idx = reinterpret_cast<int*>(smem + 2 * CHB);         // [BM]
+  float* lds_red = reinterpret_cast<float*>(smem + 2 * CHB + BM * 4);  // [VQ_WAVES]
+  const char* gimg = reinterpret_cast<const char*>(img);
+  vq_stage_chunk<CHB / 16>(gimg, smem);                          // chunk 0 flies while the z tile is loaded
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -173,19 +199,12 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
     for (int i = 0; i < 4; ++i) { best[rt][i] = INFINITY; bidx[rt][i] = 0; }
 
   const int nch = n_ep / CT;
+  __syncthreads();  // chunk 0 landed (the barrier waits for the outstanding LDS-DMA)
   for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();  // previous chunk fully consumed
-    {
-      const float4* src = reinterpret_cast<const float4*>(img + (size_t)ch * CT * DP);
-      float4* dst = reinterpret_cast<float4*>(lds_w);
-#pragma unroll
-      for (int i = 0; i < CT * DP / 4 / VQ_THREADS; ++i) dst[i * VQ_THREADS + threadIdx.x] = src[i * VQ_THREADS + threadIdx.x];
-      if constexpr ((CT * DP / 4) % VQ_THREADS != 0) {
-        const int i = (CT * DP / 4 / VQ_THREADS) * VQ_THREADS + threadIdx.x;
-        if (i < CT * DP / 4) dst[i] = src[i];
-      }
-    }
-    __syncthreads();
+    // double buffer: chunk ch+1 streams into the other buffer while this chunk feeds the MFMAs
+    if (ch + 1 < nch) vq_stage_chunk<CHB / 16>(gimg + (size_t)(ch + 1) * CHB, smem + ((ch + 1) & 1) * CHB);
+    const float* lds_w = reinterpret_cast<const float*>(smem + (ch & 1) * CHB);
+    const float* lds_ee = lds_w + CT * DP;
 #pragma unroll
     for (int ct = 0; ct < CT / 16; ++ct) {
       f32x4 acc[RT];
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
             acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt][4 * t + e], bb[e], acc[rt], 0, 0, 0);
       }
       const int code = ch * CT + ct * 16 + r;
-      const float eev = ee[code];
+      const float eev = lds_ee[ct * 16 + r];
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
@@ -215,6 +234,7 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
           bidx[rt][i] = better ? code : bidx[rt][i];
         }
     }
+    __syncthreads();  // next chunk landed + every wave is done reading this one
   }
   // ---- argmin across the 16 lanes (codes) that share this lane's rows; ties -> lowest index
 #pragma unroll
@@ -291,9 +311,11 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
   constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned short* lds_w = reinterpret_cast<unsigned short*>(smem);           // [CT][DP] bf16
-  int* lds_idx = reinterpret_cast<int*>(smem + CT * DP * 2);                 // [BM]
-  float* lds_red = reinterpret_cast<float*>(smem + CT * DP * 2 + BM * 4);    // [VQ_WAVES]
+  constexpr int CHB = CT * DP * 2 + CT * 4;                                  // one image chunk: rows + (-ee/2)
+  int* lds_idx = reinterpret_cast<int*>(smem + 2 * CHB);                     // [BM]
+  float* lds_red = reinterpret_cast<float*>(smem + 2 * CHB + BM * 4);        // [VQ_WAVES]
+  const char* gimg = reinterpret_cast<const char*>(img);
+  vq_stage_chunk<CHB / 16>(gimg, smem);                                      // chunk 0 flies while the z tile is loaded
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
@@ -330,19 +352,15 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
     for (int i = 0; i < 4; ++i) { best[rt][i] = -INFINITY; bidx[rt][i] = 0; }
 
   const int nch = n_ep / CT;
+  __syncthreads();  // chunk 0 landed (the barrier waits for the outstanding LDS-DMA)
   for (int ch = 0; ch < nch; ++ch) {
-    __syncthreads();
-    {
-      const float4* src = reinterpret_cast<const float4*>(img + (size_t)ch * CT * DP);
-      float4* dst = reinterpret_cast<float4*>(lds_w);
-#pragma unroll
-      for (int i = 0; i < CT * DP / 8 / VQ_THREADS; ++i) dst[i * VQ_THREADS + threadIdx.x] = src[i * VQ_THREADS + threadIdx.x];
-    }
-    __syncthreads();
+    if (ch + 1 < nch) vq_stage_chunk<CHB / 16>(gimg + (size_t)(ch + 1) * CHB, smem + ((ch + 1) & 1) * CHB);
+    const unsigned short* lds_w = reinterpret_cast<const unsigned short*>(smem + (ch & 1) * CHB);
+    const float* lds_nhe = reinterpret_cast<const float*>(smem + (ch & 1) * CHB + CT * DP * 2);
 #pragma unroll
     for (int ct = 0; ct < CT / 16; ++ct) {
       const int code = ch * CT + ct * 16 + r;
-      const float bias = nhe[code];  // -|w|^2/2 (or -inf for padding)
+      const float bias = lds_nhe[ct * 16 + r];  // -|w|^2/2 (or -inf for padding)
       f32x4 acc[RT];
       const unsigned short* wrow = lds_w + (ct * 16 + r) * DP;
       const int swz = r & SWZ_MASK;
@@ -366,6 +384,7 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
           bidx[rt][i] = better ? code : bidx[rt][i];
         }
     }
+    __syncthreads();  // next chunk landed + every wave is done reading this one
   }
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt)
@@ -634,11 +653,11 @@ size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_b
   const int n_ep = (n_e + CT - 1) / CT * CT;
   const int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
   CeegWs a(ws, ws_bytes);
-  size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP, dtype == CEEG_BF16 ? 2 : 4) +
+  size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4, 1) +
                 ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)vq_nslice(B) * n_e, 4);
   if (out) {
     out->ee = a.take<float>(n_ep);
-    out->img = a.take<char>((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4));
+    out->img = a.take<char>((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4);
     out->err_part = a.take<float>(nblk);
     out->hpart = a.take<uint32_t>((size_t)vq_nslice(B) * n_e);
     if (!a.ok) return 0;
@@ -649,7 +668,7 @@ size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_b
 template <int DP>
 void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, float* z_q,
                 int64_t* idx, int64_t nblk, hipStream_t st) {
-  const size_t lds = 32 * DP * 4 + 128 * 4 + VQ_WAVES * 4;
+  const size_t lds = 2 * (32 * DP * 4 + 32 * 4) + 128 * 4 + VQ_WAVES * 4;
   if (D == DP)
     hipLaunchKernelGGL((vq_main_f32<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
                        reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
@@ -660,7 +679,7 @@ void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int
 template <int DP>
 void launch_bf16(const void* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, void* z_q,
                  int64_t* idx, int64_t nblk, hipStream_t st) {
-  const size_t lds = 64 * DP * 2 + 256 * 4 + VQ_WAVES * 4;
+  const size_t lds = 2 * (64 * DP * 2 + 64 * 4) + 256 * 4 + VQ_WAVES * 4;
   if (D == DP)
     hipLaunchKernelGGL((vq_main_bf16<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(z), W, w.ee, reinterpret_cast<const unsigned short*>(w.img), B,
@@ -695,9 +714,9 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
 
   const int prep_blocks = (int)(((int64_t)n_ep * DP + 255) / 256 < 1024 ? ((int64_t)n_ep * DP + 255) / 256 : 1024);
   if (dtype == CEEG_BF16)
-    hipLaunchKernelGGL(vq_prep_kernel<true>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, w.ee, w.img);
+    hipLaunchKernelGGL(vq_prep_kernel<true>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, CT, w.ee, static_cast<char*>(w.img));
   else
-    hipLaunchKernelGGL(vq_prep_kernel<false>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, w.ee, w.img);
+    hipLaunchKernelGGL(vq_prep_kernel<false>, dim3(prep_blocks > (n_ep + 255) / 256 ? prep_blocks : (n_ep + 255) / 256), dim3(256), 0, st, W, n_e, D, n_ep, DP, CT, w.ee, static_cast<char*>(w.img));
   CEEG_CHECK_LAUNCH();
 
   if (dtype == CEEG_F32) {
