@@ -430,13 +430,14 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
           w[j] = k0 + j < D ? t : 0.f;
         }
       }
-      u16x8 o;
+      bf16x8_t ob;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float df = w[j] - ceeg_bf16_to_f32(a[rt][s][j]);
         e = __fmaf_rn(df, df, e);
-        o[j] = ceeg_f32_to_bf16(w[j]);
+        ob[j] = (__bf16)w[j];  // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
       }
+      const u16x8 o = __builtin_bit_cast(u16x8, ob);
       if constexpr (EXACT) {
         if (live) *reinterpret_cast<u16x8*>(out + k0) = o;
       } else {
@@ -469,24 +470,35 @@ __global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n
   for (int c = threadIdx.x; c < n_e; c += blockDim.x) part[(size_t)blockIdx.x * n_e + c] = h[c];
 }
 
-// one block: loss, perplexity, hist totals — every reduction in a fixed order
-__global__ void vq_finalize_kernel(const float* __restrict__ err_part, int nblk, const uint32_t* __restrict__ hpart,
-                                   int nslice, int n_e, int64_t B, int D, float beta, float* __restrict__ loss,
-                                   float* __restrict__ ppl, uint32_t* __restrict__ hist) {
-  __shared__ double red[256];
+// one block: loss, perplexity, hist totals.  Integer counts are added with LDS atomics (commutative: exact
+// and order-independent); the float sums go thread -> fixed tree in fp64.
+__global__ __launch_bounds__(1024) void vq_finalize_kernel(const float* __restrict__ err_part, int nblk,
+                                                           const uint32_t* __restrict__ hpart, int nslice, int n_e, int64_t B,
+                                                           int D, float beta, float* __restrict__ loss, float* __restrict__ ppl,
+                                                           uint32_t* __restrict__ hist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
+  __shared__ double red[1024];
+  for (int c = threadIdx.x; c < n_e; c += 1024) tot[c] = 0;
+  __syncthreads();
+  const int64_t pairs = (int64_t)nslice * n_e;
+  for (int64_t i = threadIdx.x; i < pairs; i += 1024) {
+    const uint32_t v = hpart[i];
+    if (v) atomicAdd(&tot[i % n_e], v);
+  }
   double e = 0.0;
-  for (int i = threadIdx.x; i < nblk; i += 256) e += (double)err_part[i];
+  for (int i = threadIdx.x; i < nblk; i += 1024) e += (double)err_part[i];
+  __syncthreads();
   double ent = 0.0;
-  for (int c = threadIdx.x; c < n_e; c += 256) {
-    uint32_t t = 0;
-    for (int g = 0; g < nslice; ++g) t += hpart[(size_t)g * n_e + c];
+  for (int c = threadIdx.x; c < n_e; c += 1024) {
+    const uint32_t t = tot[c];
     if (hist) hist[c] = t;
     const float p = (float)t / (float)B;
     ent += (double)(p * logf(p + 1e-10f));
   }
   red[threadIdx.x] = e;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -494,7 +506,7 @@ __global__ void vq_finalize_kernel(const float* __restrict__ err_part, int nblk,
   __syncthreads();
   red[threadIdx.x] = ent;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
     __syncthreads();
   }
@@ -741,10 +753,13 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
   }
   CEEG_CHECK_LAUNCH();
 
-  const int nslice = (int)vq_nslice(B);
-  hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.hpart);
+  // forward histogram: at most 128 slices (the finalize kernel reads nslice*n_e counts)
+  int64_t rows_per = (B + 127) / 128;
+  rows_per = rows_per < VQ_HIST_ROWS ? VQ_HIST_ROWS : (rows_per + 255) / 256 * 256;
+  const int nslice = (int)((B + rows_per - 1) / rows_per);
+  hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, rows_per, w.hpart);
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, w.err_part, (int)nblk, w.hpart, nslice, n_e, B, D, beta,
+  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(1024), (size_t)n_e * 4, st, w.err_part, (int)nblk, w.hpart, nslice, n_e, B, D, beta,
                      loss, perplexity, hist);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
