@@ -30,7 +30,7 @@ SIGNATURES = {
     "ceeg_csr_transpose": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_gcn_norm": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp]),
     "ceeg_spmm_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
-    "ceeg_spmm_csr": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_spmm_csr": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_reparam_kl_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_reparam_kl_fwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _c_i64, _c_int, _c_f32, _c_int, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_reparam_kl_bwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _vp, _vp, _c_i64, _c_int, _c_f32, _c_int, _c_int, _vp, _c_i64, _vp, _c_i64, _vp]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "ceeg_edge_bce_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_decoder_fused_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
     "ceeg_decoder_fused_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
-    "ceeg_decoder_fused_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_decoder_fused_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
 }
 

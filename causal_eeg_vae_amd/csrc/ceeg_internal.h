@@ -83,6 +83,7 @@ __device__ __forceinline__ float2 ceeg_box_muller(uint32_t x0, uint32_t x1) {
 // gathered column index and on the output row, and a device-side scale applied to the row sum.
 struct CeegSpmmEx {
   int64_t row_a = 1, row_b = 0, col_a = 1, col_b = 0, mod = 1;
+  int64_t max_row_nnz = -1;  // longest row if the caller knows it (<0: unknown -> the long-row pass always runs)
   const float* scale = nullptr;
 };
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,

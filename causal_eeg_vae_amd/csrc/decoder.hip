@@ -274,7 +274,8 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
                                       const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
                                       const float* coef_pos, const float* coef_neg, const float* gscale,
-                                      float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream) {
+                                      float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
+                                      void* ws, size_t ws_bytes, void* stream) {
   if (!z || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0) return CEEG_EINVAL;
   if (nnz > 0 && (!col || !t_col || !t_perm || !coef_pos || !coef_neg)) return CEEG_EINVAL;
   if (sig_a <= 0 || sig_b < 0 || sig_b >= N || sig_ainv <= 0) return CEEG_EINVAL;
@@ -283,18 +284,19 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   // (1) n as dst of positives:            dz[n]  = gp * sum_{p in row n} cp[p] z[col p]
-  CeegSpmmEx e1; e1.mod = N; e1.scale = gscale + 0;
+  CeegSpmmEx e1; e1.mod = N; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz;
+  CeegSpmmEx e2 = e1; e2.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_pos, nullptr, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, e1);
   if (rc != CEEG_OK) return rc;
   // (2) n as src of positives:            dz[n] += gp * sum_{q in trow n} cp[tperm q] z[tcol q]
-  rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e1);
+  rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e2);
   if (rc != CEEG_OK) return rc;
   // (3) n = sigma(r) as negative endpoint: dz[sigma(r)] += gn * sum_{p in row r} cn[p] z[col p]
-  CeegSpmmEx e3; e3.mod = N; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b;
+  CeegSpmmEx e3; e3.mod = N; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_neg, nullptr, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e3);
   if (rc != CEEG_OK) return rc;
   // (4) n as src of negatives:            dz[n] += gn * sum_{q in trow n} cn[tperm q] z[sigma(tcol q)]
-  CeegSpmmEx e4; e4.mod = N; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b;
+  CeegSpmmEx e4; e4.mod = N; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e4);
   return rc;
 }

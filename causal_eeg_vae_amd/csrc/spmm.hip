@@ -296,7 +296,7 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
                 int64_t ldx, int64_t N, int64_t nnz, int F, int fbase, const float* bias, int relu, int accumulate,
                 float* out, int64_t ldo, float* partial, unsigned int* queue, hipStream_t st, const CeegSpmmEx& ex) {
   const int64_t nchunk = (nnz + SPMM_CHUNK - 1) / SPMM_CHUNK;
-  if (nchunk > 0) {
+  if (nchunk > 0 && !(ex.max_row_nnz >= 0 && ex.max_row_nnz <= SPMM_CHUNK)) {  // skipped when the caller knows there is no long row
     hipLaunchKernelGGL(spmm_long_kernel<LPR>, dim3((unsigned)((nchunk + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64), 0, st,
                        rowptr, col, val, vperm, X, ldx, N, F, fbase, partial, ex);
     CEEG_CHECK_LAUNCH();
@@ -356,9 +356,10 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
 
 extern "C" int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                              const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
-                             int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream) {
+                             int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream) {
   CeegSpmmEx ex;
   ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }

@@ -57,6 +57,10 @@ class CsrPair:
                                         self.t_col.data_ptr(), self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _lib.stream()), "ceeg_csr_transpose")
 
+        # longest row of each orientation (graph-construction time): lets SpMM skip its long-row pass
+        self.max_row = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if N > 0 else 0
+        self.max_trow = int((self.t_rowptr[1:] - self.t_rowptr[:-1]).max().item()) if N > 0 else 0
+
     @property
     def device(self):
         return self.rowptr.device
@@ -95,7 +99,7 @@ def _as_graph(g, num_nodes):
     return EventGraph(g, num_nodes)
 
 
-def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False):
+def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1):
     L = _lib.lib()
     nnz = col.shape[0]
     F = x.shape[1]
@@ -105,7 +109,7 @@ def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, a
     with _lib.timed(f"spmm_F{F}"):
         _lib.check(L.ceeg_spmm_csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
                                    n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
-                                   ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr")
+                                   int(max_row), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr")
     return out
 
 
@@ -117,7 +121,7 @@ class _GcnAggregate(torch.autograd.Function):
         _lib.require_cuda(h)
         h = h.contiguous()
         g = graph.gcn
-        out = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, bias=bias, relu=relu)
+        out = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, bias=bias, relu=relu, max_row=g.max_row)
         ctx.graph, ctx.relu, ctx.has_bias = graph, bool(relu), bias is not None
         if relu:
             ctx.save_for_backward(out)
@@ -131,7 +135,7 @@ class _GcnAggregate(torch.autograd.Function):
             (out,) = ctx.saved_tensors
             grad = grad * (out > 0)
         dbias = grad.sum(dim=0) if ctx.has_bias else None
-        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_val, g.t_perm, grad, graph.num_nodes) if ctx.needs_input_grad[0] else None
+        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_val, g.t_perm, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
 
@@ -291,8 +295,8 @@ class _EdgeBCE(torch.autograd.Function):
         pair = ctx.pair if ctx.pair is not None else CsrPair(ctx.edge_index, N, self_loops=False)
         # CSR rows = edge_index[1] (j), cols = edge_index[0] (i); perm maps CSR position -> edge id
         cv = coef[pair.perm.long()] * g
-        dz = _spmm(pair.rowptr, pair.col, cv, None, z, N)
-        _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True)
+        dz = _spmm(pair.rowptr, pair.col, cv, None, z, N, max_row=pair.max_row)
+        _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True, max_row=pair.max_trow)
         return dz, None, None, None
 
 
@@ -386,7 +390,7 @@ class _FusedDecoder(torch.autograd.Function):
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
                                             p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, cp.data_ptr(),
-                                            cn.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(),
+                                            cn.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
                                             _lib.stream()), "ceeg_decoder_fused_bwd")
         return dz, None, None, None, None
 

@@ -115,11 +115,12 @@ int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm
  * Summation order is p ascending in fixed blocks (SPMM_CHUNK) whose partial sums are added in block order
  * -> bitwise reproducible, no atomics.  X [*,ldx] fp32, out [N,ldo] fp32, F % 4 == 0, 4 <= F <= 1024,
  * ldx/ldo multiples of 4, pointers 16-byte aligned.  bias [F] or NULL; relu != 0 applies max(.,0).
- * accumulate != 0 adds into `out` instead of overwriting it. */
+ * accumulate != 0 adds into `out` instead of overwriting it.  max_row_nnz: the longest row if known (lets the
+ * long-row pass be skipped when no row exceeds the chunk), < 0 when unknown. */
 size_t ceeg_spmm_ws_bytes(int64_t N, int64_t nnz, int F);
 int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                   const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
-                  int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+                  int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A3+A4  VGAE.reparametrize + VGAE.kl_loss (upstream PyG; anchors: MAX_LOGSTD scripts/run.py:13,
@@ -180,7 +181,8 @@ int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, c
                            const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
                            const float* coef_pos, const float* coef_neg, const float* gscale,
-                           float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+                           float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
