@@ -85,6 +85,8 @@ struct CeegSpmmEx {
   int64_t row_a = 1, row_b = 0, col_a = 1, col_b = 0, mod = 1;
   int64_t max_row_nnz = -1;  // longest row if the caller knows it (<0: unknown -> the long-row pass always runs)
   const float* scale = nullptr;
+  const float* addend = nullptr;  // [N, ld_add]: added to row r's sum before the scale (row index BEFORE the row map)
+  int64_t ld_add = 0;
 };
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                      const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,

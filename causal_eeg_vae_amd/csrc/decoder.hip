@@ -109,72 +109,175 @@ __device__ __forceinline__ bool sorted_has(const int32_t* __restrict__ col, int 
   return lo < end && col[lo] == s;
 }
 
-template <int LPR>
+// Transposed butterfly: every lane enters with NV partial sums (one per (step, kind) of a round) that must each be
+// summed over the LPR lanes of its group.  Instead of NV full butterflies (NV * log2(LPR) exchanges) each exchange
+// step hands HALF of the values to the partner lane and keeps the other half, so the count halves every step:
+// NV/2 + NV/4 + ... exchanges.  After H = min(log2 LPR, log2 NV) halvings a lane holds NVF = NV >> H finished
+// values (slot i = value (fl >> (M-H)) * NVF + i); left-over strides finish as plain butterflies.
+template <int STRIDE, int NV>
+struct DecTRed {
+  static __device__ __forceinline__ void run(float* v, int fl) {
+    if constexpr (STRIDE >= 1) {
+      if constexpr (NV > 1) {
+        const bool up = (fl & STRIDE) != 0;
+#pragma unroll
+        for (int i = 0; i < NV / 2; ++i) {
+          const float send = up ? v[i] : v[i + NV / 2];
+          const float keep = up ? v[i + NV / 2] : v[i];
+          v[i] = keep + __shfl_xor(send, STRIDE, 64);
+        }
+        DecTRed<STRIDE / 2, NV / 2>::run(v, fl);
+      } else {
+        v[0] += __shfl_xor(v[0], STRIDE, 64);
+        DecTRed<STRIDE / 2, 1>::run(v, fl);
+      }
+    }
+  }
+};
+constexpr int dec_log2(int x) { return x <= 1 ? 0 : 1 + dec_log2(x / 2); }
+
+struct DecRowState {
+  float4 zr, zs;      // this lane's piece of z[r] and z[sigma(r)]
+  float4 ga, gb;      // running sum_p cp[p] z[col p] / sum_p cn[p] z[col p] over this lane's sub-group of entries
+  float s_pos, s_neg, s_cnt;
+};
+
+// One round = T gather steps (T*G entries of the current 64-entry batch, starting at step i0): gathers in flight together,
+// 2T dot products reduced by the transposed butterfly, ONE evaluation of the sigmoid/log/derivative per 2T*G values
+// (spread over the lanes instead of repeated per step), then the coefficients go back to the lanes that still hold
+// the gathered pieces for the row-side gradient sums.
+template <int LPR, int T, bool GRAD>
+__device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t ldz, int my_c, int my_valid, int base, int i0, int ns, int n,
+                                          int lane, bool fl_ok, float* __restrict__ coef_pos, float* __restrict__ coef_neg,
+                                          DecRowState& st) {
+  constexpr int G = 64 / LPR;
+  constexpr int M = dec_log2(LPR);
+  constexpr int NV = 2 * T;
+  constexpr int H = M < dec_log2(NV) ? M : dec_log2(NV);
+  constexpr int NVF = NV >> H;
+  const int fl = lane % LPR, sub = lane / LPR;
+  float4 x[T];
+  float v[NV];
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    const int j = (i0 + k) * G + sub;
+    const int c = __shfl(my_c, j & 63, 64);
+    x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i0 + k < ns && j < n && fl_ok) x[k] = *reinterpret_cast<const float4*>(z + (int64_t)c * ldz + 4 * fl);
+  }
+#pragma unroll
+  for (int k = 0; k < T; ++k) {
+    v[k] = dot4(x[k], st.zr);
+    v[T + k] = dot4(x[k], st.zs);
+  }
+  DecTRed<LPR / 2, NV>::run(v, fl);
+  const int top = fl >> (M - H);
+  const bool writer = (fl & ((1 << (M - H)) - 1)) == 0;
+  float cf[NVF];
+#pragma unroll
+  for (int i = 0; i < NVF; ++i) {
+    const int idx = top * NVF + i;
+    const int kind = idx / T, k = idx % T;
+    const int j = (i0 + k) * G + sub;
+    const bool ok = (i0 + k < ns) && j < n;
+    const int vld = __shfl(my_valid, j & 63, 64);
+    const float s = dec_sigmoid(v[i]);
+    const float om = 1.0f - s;
+    const float a = kind ? om : s;
+    const float sso = s * om;
+    float term = -logf(a + DEC_EPS);
+    float coef = (kind ? sso : -sso) / (a + DEC_EPS);
+    const bool live = ok && (kind == 0 || vld != 0);
+    if (!live) { term = 0.f; coef = 0.f; }
+    if (ok && writer) {
+      (kind ? coef_neg : coef_pos)[base + j] = coef;
+      if (kind == 0) st.s_pos += term;
+      else if (vld) { st.s_neg += term; st.s_cnt += 1.0f; }
+    }
+    cf[i] = coef;
+  }
+  if constexpr (GRAD) {
+    const int gbase = lane & ~(LPR - 1);
+#pragma unroll
+    for (int k = 0; k < T; ++k) {
+      const int ip = k, in = T + k;
+      const float cp = __shfl(cf[ip % NVF], gbase | ((ip / NVF) << (M - H)), 64);
+      const float cn = __shfl(cf[in % NVF], gbase | ((in / NVF) << (M - H)), 64);
+      st.ga.x = __fmaf_rn(cp, x[k].x, st.ga.x); st.ga.y = __fmaf_rn(cp, x[k].y, st.ga.y);
+      st.ga.z = __fmaf_rn(cp, x[k].z, st.ga.z); st.ga.w = __fmaf_rn(cp, x[k].w, st.ga.w);
+      st.gb.x = __fmaf_rn(cn, x[k].x, st.gb.x); st.gb.y = __fmaf_rn(cn, x[k].y, st.gb.y);
+      st.gb.z = __fmaf_rn(cn, x[k].z, st.gb.z); st.gb.w = __fmaf_rn(cn, x[k].w, st.gb.w);
+    }
+  }
+}
+
+// Row r of the dst-sorted CSR: positives (r, col p), negatives (col p, sigma(r)) - both share the gather of z[col p].
+// GRAD also leaves the row-side gradient sums (unscaled):  grow_pos[r] = sum_p cp[p] z[col p],
+// grow_neg[sigma(r)] = sum_p cn[p] z[col p]  (sigma is a bijection: every row of both tables is written once).
+template <int LPR, bool GRAD>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int D,
-    int64_t sig_a, int64_t sig_b, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ part) {
+    int64_t sig_a, int64_t sig_b, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
+    float* __restrict__ grow_neg, int64_t ldg, float* __restrict__ part) {
   __shared__ float red[3 * DEC_WAVES];
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
-  const int fl = lane % LPR, sub = lane / LPR;
+  const int fl = lane % LPR;
   const bool fl_ok = 4 * fl < D;
   const int64_t wave = (int64_t)blockIdx.x * DEC_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * DEC_WAVES;
-  float s_pos = 0.f, s_neg = 0.f, s_cnt = 0.f;
+  DecRowState st;
+  st.s_pos = st.s_neg = st.s_cnt = 0.f;
   // contiguous slab of rows per wave: neighbouring rows (time-local events) stay on one CU / XCD
   const int64_t per = (N + nwaves - 1) / nwaves;
   const int64_t r_lo = wave * per, r_hi = r_lo + per < N ? r_lo + per : N;
   for (int64_t r = r_lo; r < r_hi; ++r) {
     const int p_lo = rowptr[r], p_hi = rowptr[r + 1];
-    if (p_lo == p_hi) continue;
     const int64_t sr = (int64_t)(((uint64_t)sig_a * (uint64_t)r + (uint64_t)sig_b) % (uint64_t)N);
-    float4 zr = make_float4(0.f, 0.f, 0.f, 0.f), zs = zr;
-    if (fl_ok) {
-      zr = *reinterpret_cast<const float4*>(z + r * ldz + 4 * fl);
-      zs = *reinterpret_cast<const float4*>(z + sr * ldz + 4 * fl);
-    }
-    const int s_lo = rowptr[sr], s_hi = rowptr[sr + 1];
-    for (int base = p_lo; base < p_hi; base += 64) {
-      const int n = p_hi - base < 64 ? p_hi - base : 64;
-      int my_c = 0, my_valid = 0;
-      if (lane < n) {
-        my_c = col[base + lane];
-        my_valid = (my_c != (int)sr && !sorted_has(col, s_lo, s_hi, my_c)) ? 1 : 0;
+    st.ga = make_float4(0.f, 0.f, 0.f, 0.f);
+    st.gb = st.ga;
+    if (p_lo != p_hi) {
+      st.zr = st.ga;
+      st.zs = st.ga;
+      if (fl_ok) {
+        st.zr = *reinterpret_cast<const float4*>(z + r * ldz + 4 * fl);
+        st.zs = *reinterpret_cast<const float4*>(z + sr * ldz + 4 * fl);
       }
-      const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
-      for (int i0 = 0; i0 < ns; i0 += 4) {
-        // up to 4 gathers in flight, then the 4 pairs of dot products
-        float4 x[4];
-        int cv[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int j = (i0 + k) * G + sub;
-          const int c = __shfl(my_c, j & 63, 64);
-          cv[k] = __shfl(my_valid, j & 63, 64);
-          x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (i0 + k < ns && j < n && fl_ok) x[k] = *reinterpret_cast<const float4*>(z + (int64_t)c * ldz + 4 * fl);
+      const int s_lo = rowptr[sr], s_hi = rowptr[sr + 1];
+      for (int base = p_lo; base < p_hi; base += 64) {
+        const int n = p_hi - base < 64 ? p_hi - base : 64;
+        int my_c = 0, my_valid = 0;
+        if (lane < n) {
+          my_c = col[base + lane];
+          my_valid = (my_c != (int)sr && !sorted_has(col, s_lo, s_hi, my_c)) ? 1 : 0;
         }
+        const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
+        int i0 = 0;
+        for (; i0 + 8 <= ns; i0 += 8) dec_round<LPR, 8, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        const int rem = ns - i0;  // one round of the next power of two covers the tail
+        if (rem > 4) dec_round<LPR, 8, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        else if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+      }
+    }
+    if constexpr (GRAD) {
+      if constexpr (G > 1) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (i0 + k >= ns) break;  // wave-uniform
-          const int j = (i0 + k) * G + sub;
-          const bool ok = j < n;
-          const float dp = group_sum<LPR>(dot4(x[k], zr));
-          const float dn = group_sum<LPR>(dot4(x[k], zs));
-          if (ok && fl == 0) {
-            float tp, cp, tn, cn;
-            dec_pos(dp, tp, cp);
-            dec_neg(dn, tn, cn);
-            coef_pos[base + j] = cp;
-            coef_neg[base + j] = cv[k] ? cn : 0.f;
-            s_pos += tp;
-            if (cv[k]) { s_neg += tn; s_cnt += 1.0f; }
-          }
+        for (int o = 32; o >= LPR; o >>= 1) {
+          st.ga.x += __shfl_xor(st.ga.x, o, 64); st.ga.y += __shfl_xor(st.ga.y, o, 64);
+          st.ga.z += __shfl_xor(st.ga.z, o, 64); st.ga.w += __shfl_xor(st.ga.w, o, 64);
+          st.gb.x += __shfl_xor(st.gb.x, o, 64); st.gb.y += __shfl_xor(st.gb.y, o, 64);
+          st.gb.z += __shfl_xor(st.gb.z, o, 64); st.gb.w += __shfl_xor(st.gb.w, o, 64);
         }
+      }
+      if (lane < LPR && fl_ok) {
+        *reinterpret_cast<float4*>(grow_pos + r * ldg + 4 * fl) = st.ga;
+        *reinterpret_cast<float4*>(grow_neg + sr * ldg + 4 * fl) = st.gb;
       }
     }
   }
-  dec_block_out(s_pos, s_neg, s_cnt, red, part);
+  dec_block_out(st.s_pos, st.s_neg, st.s_cnt, red, part);
 }
 
 int dec_lpr(int D) {
@@ -235,8 +338,10 @@ extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
 
 extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b,
-                                      float* coef_pos, float* coef_neg, float* sums,
-                                      void* ws, size_t ws_bytes, void* stream) {
+                                      float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
+                                      float* sums, void* ws, size_t ws_bytes, void* stream) {
+  if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
+  if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
   if (!z || !rowptr || !sums || N <= 0 || nnz < 0 || D <= 0 || (nnz > 0 && (!col || !coef_pos || !coef_neg))) return CEEG_EINVAL;
   if ((D % 4) != 0 || D > 256 || (ldz % 4) != 0 || ldz < D || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (sig_a <= 0 || sig_a >= N + (N == 1) || sig_b < 0 || sig_b >= N) return CEEG_EINVAL;
@@ -248,10 +353,14 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   int64_t nb = (N + DEC_WAVES * 4 - 1) / (DEC_WAVES * 4);  // ~4 rows per wave at least
   if (nb < 1) nb = 1;
   const int nblk = (int)(nb < DEC_MAX_BLOCKS ? nb : DEC_MAX_BLOCKS);
-#define CEEG_DEC_CASE(L)                                                                                                      \
-  case L:                                                                                                                     \
-    hipLaunchKernelGGL(decoder_fused_fwd_kernel<L>, dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
-                       sig_b, coef_pos, coef_neg, part);                                                                      \
+#define CEEG_DEC_CASE(L)                                                                                                              \
+  case L:                                                                                                                             \
+    if (grow_pos)                                                                                                                     \
+      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
+                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, part);                                                   \
+    else                                                                                                                              \
+      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
+                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, part);                                                   \
     break;
   switch (lpr) {
     CEEG_DEC_CASE(1)
@@ -273,16 +382,28 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
 extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                                       const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
-                                      const float* coef_pos, const float* coef_neg, const float* gscale,
-                                      float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
+                                      const float* coef_pos, const float* coef_neg, const float* grow_pos,
+                                      const float* grow_neg, int64_t ldg, const float* gscale, float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                                       void* ws, size_t ws_bytes, void* stream) {
   if (!z || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0) return CEEG_EINVAL;
   if (nnz > 0 && (!col || !t_col || !t_perm || !coef_pos || !coef_neg)) return CEEG_EINVAL;
   if (sig_a <= 0 || sig_b < 0 || sig_b >= N || sig_ainv <= 0) return CEEG_EINVAL;
   if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)N) != (uint64_t)(1 % N)) return CEEG_EINVAL;
   if (ws_bytes < ceeg_decoder_fused_ws_bytes(N, nnz, D)) return CEEG_EWORKSPACE;
+  if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
+  if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
+  if (grow_pos) {
+    // the forward already holds the row-side sums (terms (1) and (3) below); two transposed passes finish the job:
+    //   dz[n]  = gp * (grow_pos[n] + sum_{q in trow n} cp[tperm q] z[tcol q])
+    //   dz[n] += gn * (grow_neg[n] + sum_{q in trow n} cn[tperm q] z[sigma(tcol q)])
+    CeegSpmmEx t2; t2.mod = N; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg;
+    rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, t2);
+    if (rc != CEEG_OK) return rc;
+    CeegSpmmEx t4 = t2; t4.scale = gscale + 1; t4.col_a = sig_a; t4.col_b = sig_b; t4.addend = grow_neg;
+    return ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, t4);
+  }
   // (1) n as dst of positives:            dz[n]  = gp * sum_{p in row n} cp[p] z[col p]
   CeegSpmmEx e1; e1.mod = N; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz;
   CeegSpmmEx e2 = e1; e2.max_row_nnz = max_trow_nnz;

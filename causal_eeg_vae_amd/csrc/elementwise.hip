@@ -1,0 +1,126 @@
+// Small streaming kernels around the dense transforms of a GCN layer (HBM-bound, one pass each):
+//   ceeg_bias_relu      : y = relu(y + b) in place (epilogue of (A_hat x) W^T)
+//   ceeg_relu_bwd_colsum: gm = g * (y > 0) (gm may alias g) AND colsum[f] = sum_n g[n,f] (the bias gradient) in one pass
+//   ceeg_colsum         : colsum[f] = sum_n g[n,f]
+// Column sums are deterministic: per-block partial rows in a fixed order, then one fp64 pass over the blocks.
+// They stand behind torch.relu / its backward / bias.grad of the reference-style host code (no reference
+// counterpart of their own: PyG GCNConv adds its bias and autograd reduces it).
+#include "ceeg_internal.h"
+
+namespace {
+
+constexpr int EW_THREADS = 256;
+constexpr int EW_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(EW_THREADS) void bias_relu_kernel(float* __restrict__ y, int64_t ld, int64_t N, int F,
+                                                               const float* __restrict__ bias, int relu) {
+  const int fq = F / 4;
+  const int64_t total = N * fq;
+  for (int64_t g = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; g < total; g += (int64_t)gridDim.x * EW_THREADS) {
+    const int64_t n = g / fq;
+    const int f = (int)(g - n * fq) * 4;
+    float4 v = *reinterpret_cast<float4*>(y + n * ld + f);
+    if (bias) {
+      const float4 b = *reinterpret_cast<const float4*>(bias + f);
+      v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    *reinterpret_cast<float4*>(y + n * ld + f) = v;
+  }
+}
+
+// block b owns rows [b*rows_per, ...); thread t owns column quad (t % fq) and walks rows (t / fq), +rpb, ...
+template <bool MASK>
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* g, int64_t ldg, const float* __restrict__ y, int64_t ldy,
+                                                            float* gm, int64_t ldm, int64_t N, int F, int64_t rows_per,
+                                                            float* __restrict__ part /* [grid][F] */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* red = reinterpret_cast<float4*>(smem);  // [EW_THREADS]
+  const int fq = F / 4;              // <= EW_THREADS
+  const int rpb = EW_THREADS / fq;   // rows walked concurrently by the block
+  const int cq = threadIdx.x % fq, rr = threadIdx.x / fq;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per;
+  const int64_t hi = lo + rows_per < N ? lo + rows_per : N;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rr < rpb) {
+    for (int64_t n = lo + rr; n < hi; n += rpb) {
+      float4 v = *reinterpret_cast<const float4*>(g + n * ldg + 4 * cq);
+      if (MASK) {
+        const float4 o = *reinterpret_cast<const float4*>(y + n * ldy + 4 * cq);
+        v.x = o.x > 0.f ? v.x : 0.f; v.y = o.y > 0.f ? v.y : 0.f; v.z = o.z > 0.f ? v.z : 0.f; v.w = o.w > 0.f ? v.w : 0.f;
+        *reinterpret_cast<float4*>(gm + n * ldm + 4 * cq) = v;
+      }
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (rr == 0) {  // fixed order over the block's row groups
+    for (int k = 1; k < rpb; ++k) {
+      const float4 t = red[k * fq + cq];
+      acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * F + 4 * cq) = acc;
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int F, float* __restrict__ out) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= F) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * F + f];
+  out[f] = (float)s;
+}
+
+int ew_blocks(int64_t work) {
+  int64_t b = (work + EW_THREADS - 1) / EW_THREADS;
+  if (b < 1) b = 1;
+  return (int)(b < 4 * EW_MAX_BLOCKS ? b : 4 * EW_MAX_BLOCKS);
+}
+
+int colsum_launch(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F, float* colsum,
+                  void* ws, size_t ws_bytes, hipStream_t st) {
+  if (!g || !colsum || N <= 0 || F < 4 || (F % 4) != 0 || F > 4 * EW_THREADS || ldg < F || (ldg % 4) != 0) return CEEG_EINVAL;
+  if (y && (!gm || ldy < F || (ldy % 4) != 0 || ldm < F || (ldm % 4) != 0)) return CEEG_EINVAL;
+  if (!ceeg_aligned(g, 16) || (y && (!ceeg_aligned(y, 16) || !ceeg_aligned(gm, 16)))) return CEEG_EINVAL;
+  if (ws_bytes < ceeg_colsum_ws_bytes(N, F) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  int64_t nblk = (N + 255) / 256;
+  if (nblk > EW_MAX_BLOCKS) nblk = EW_MAX_BLOCKS;
+  const int64_t rows_per = (N + nblk - 1) / nblk;
+  nblk = (N + rows_per - 1) / rows_per;
+  float* part = static_cast<float*>(ws);
+  if (y)
+    hipLaunchKernelGGL(colsum_kernel<true>, dim3((unsigned)nblk), dim3(EW_THREADS), EW_THREADS * 16, st, g, ldg, y, ldy, gm, ldm, N, F, rows_per, part);
+  else
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3((unsigned)nblk), dim3(EW_THREADS), EW_THREADS * 16, st, g, ldg, y, ldy, gm, ldm, N, F, rows_per, part);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((F + 255) / 256), dim3(256), 0, st, part, (int)nblk, F, colsum);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+}  // namespace
+
+extern "C" int ceeg_bias_relu(float* y, int64_t ld, int64_t N, int F, const float* bias, int relu, void* stream) {
+  if (!y || N <= 0 || F < 4 || (F % 4) != 0 || ld < F || (ld % 4) != 0) return CEEG_EINVAL;
+  if (!ceeg_aligned(y, 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
+  hipLaunchKernelGGL(bias_relu_kernel, dim3(ew_blocks(N * (F / 4))), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), y, ld, N, F,
+                     bias, relu);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" size_t ceeg_colsum_ws_bytes(int64_t N, int F) {
+  if (N <= 0 || F <= 0) return 0;
+  return ceeg_ws_part((size_t)EW_MAX_BLOCKS * F, 4);
+}
+
+extern "C" int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F,
+                                    float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  if (!y) return CEEG_EINVAL;
+  return colsum_launch(g, ldg, y, ldy, gm, ldm, N, F, colsum, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, void* ws, size_t ws_bytes, void* stream) {
+  return colsum_launch(g, ldg, nullptr, 0, nullptr, 0, N, F, colsum, ws, ws_bytes, static_cast<hipStream_t>(stream));
+}

@@ -252,6 +252,10 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         }
       }
       if (lane < LPR && fl_ok) {
+        if (ex.addend) {
+          const float4 a = *reinterpret_cast<const float4*>(ex.addend + r * ex.ld_add + foff);
+          acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        }
         if (ex.scale) {
           const float sc = ex.scale[0];
           acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;

@@ -113,6 +113,30 @@ def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, a
     return out
 
 
+def _colsum(g):
+    """Deterministic column sums of a [N, F] fp32 matrix (bias gradients)."""
+    L = _lib.lib()
+    n, F = g.shape
+    out = torch.empty(F, dtype=torch.float32, device=g.device)
+    ws = _lib.workspace(L.ceeg_colsum_ws_bytes(n, F), g.device)
+    with _lib.timed("colsum"):
+        _lib.check(L.ceeg_colsum(g.data_ptr(), g.stride(0), n, F, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_colsum")
+    return out
+
+
+def _relu_bwd_colsum(g, y):
+    """One pass: gm = g * (y > 0) and its column sums (autograd's incoming gradient is left untouched)."""
+    L = _lib.lib()
+    n, F = g.shape
+    gm = torch.empty(n, F, dtype=torch.float32, device=g.device)
+    out = torch.empty(F, dtype=torch.float32, device=g.device)
+    ws = _lib.workspace(L.ceeg_colsum_ws_bytes(n, F), g.device)
+    with _lib.timed("relu_bwd_colsum"):
+        _lib.check(L.ceeg_relu_bwd_colsum(g.data_ptr(), g.stride(0), y.data_ptr(), y.stride(0), gm.data_ptr(), gm.stride(0), n, F, out.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_relu_bwd_colsum")
+    return gm, out
+
+
 class _GcnAggregate(torch.autograd.Function):
     """out = act(A_hat @ h + b); backward dh = A_hat^T @ g through the transposed CSR (values via t_perm)."""
 
@@ -133,8 +157,9 @@ class _GcnAggregate(torch.autograd.Function):
         grad = grad.contiguous()
         if ctx.relu:
             (out,) = ctx.saved_tensors
-            grad = grad * (out > 0)
-        dbias = grad.sum(dim=0) if ctx.has_bias else None
+            grad, dbias = _relu_bwd_colsum(grad, out)
+        else:
+            dbias = _colsum(grad) if ctx.has_bias else None
         dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_val, g.t_perm, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
@@ -160,17 +185,28 @@ class _Linear(torch.autograd.Function):
     over K into a batched product whose S partial results are summed in a fixed order (deterministic)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, relu=False):
         wt = weight.t().contiguous()  # [in, out]; out*in floats
         y = torch.mm(x, wt) if bias is None else torch.addmm(bias, x, wt)
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        if relu:
+            L = _lib.lib()
+            with _lib.timed("bias_relu"):
+                _lib.check(L.ceeg_bias_relu(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], None, 1, _lib.stream()), "ceeg_bias_relu")
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
+        ctx.has_bias, ctx.relu = bias is not None, bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, weight = ctx.saved_tensors
-        g = g.contiguous()
+        db = None
+        if ctx.relu:
+            x, weight, y = ctx.saved_tensors
+            g, db = _relu_bwd_colsum(g.contiguous(), y)
+        else:
+            x, weight = ctx.saved_tensors
+            g = g.contiguous()
         dx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None  # [N,out] @ [out,in]: NN
         dw = None
         if ctx.needs_input_grad[1]:
@@ -180,8 +216,9 @@ class _Linear(torch.autograd.Function):
                 dw = torch.bmm(g.view(s, n // s, -1).transpose(1, 2), x.contiguous().view(s, n // s, -1)).sum(dim=0)
             else:
                 dw = g.t() @ x
-        db = g.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(g)
+        return dx, dw, (db if ctx.has_bias else None), None
 
 
 class _Lin(nn.Module):
@@ -211,9 +248,8 @@ class GCNConv(nn.Module):
             graph = EventGraph(graph, x.shape[0], edge_weight)
         if self.aggregate_first:
             ax = _GcnAggregate.apply(x, None, graph, False)
-            out = _Linear.apply(ax, self.lin.weight, self.bias)
-            return torch.relu(out) if relu else out
-        return _GcnAggregate.apply(_Linear.apply(x, self.lin.weight, None), self.bias, graph, relu)
+            return _Linear.apply(ax, self.lin.weight, self.bias, bool(relu))
+        return _GcnAggregate.apply(_Linear.apply(x, self.lin.weight, None, False), self.bias, graph, relu)
 
 
 # ==================================================================================================
@@ -359,7 +395,7 @@ class _FusedDecoder(torch.autograd.Function):
     """recon_loss with permutation-structured negatives: one gather pass for both terms (ceeg_decoder_fused_*)."""
 
     @staticmethod
-    def forward(ctx, z, graph, a, b, ainv):
+    def forward(ctx, z, graph, a, b, ainv, row_sums=True):
         _lib.require_cuda(z)
         L = _lib.lib()
         z = z.contiguous()
@@ -368,10 +404,14 @@ class _FusedDecoder(torch.autograd.Function):
         cp = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
         cn = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
         sums = torch.empty(3, dtype=torch.float32, device=z.device)
+        # with a gradient wanted, the forward also leaves the row-side halves of dz (two [N, D] tables)
+        grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
-        _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b,
-                                            cp.data_ptr(), cn.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(),
-                                            _lib.stream()), "ceeg_decoder_fused_fwd")
+        with _lib.timed("decoder_fwd"):
+            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b,
+                                                cp.data_ptr(), cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
+                                                sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
+        ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
         ctx.save_for_backward(z, cp, cn, inv)
         ctx.graph, ctx.sig = graph, (a, b, ainv)
@@ -388,11 +428,15 @@ class _FusedDecoder(torch.autograd.Function):
         gscale = (inv * g).contiguous()
         dz = torch.empty_like(z)
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
-        _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
-                                            p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, cp.data_ptr(),
-                                            cn.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
-                                            _lib.stream()), "ceeg_decoder_fused_bwd")
-        return dz, None, None, None, None
+        grow = ctx.grow
+        with _lib.timed("decoder_bwd"):
+            _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
+                                                p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, cp.data_ptr(),
+                                                cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
+                                                gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
+                                                _lib.stream()), "ceeg_decoder_fused_bwd")
+        ctx.grow = None
+        return dz, None, None, None, None, None
 
 
 # ==================================================================================================

@@ -164,25 +164,43 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
  * One gather of z[col[p]] serves both dots.  Outputs coef_pos[nnz], coef_neg[nnz] (unscaled d term/dv),
  * sums[0]=sum pos terms, sums[1]=sum valid neg terms, sums[2]=number of valid negatives (as float),
  * all written to `sums` (3 floats, device).  rowptr/col: CSR WITHOUT self-loops (ceeg_csr_build
- * self_loops=0). */
+ * self_loops=0).
+ * grow_pos / grow_neg ([N, ldg] fp32, both or neither; NULL when no gradient is wanted): the row-side halves of
+ * dz, accumulated while the gathered pieces are still in registers (unscaled):
+ *   grow_pos[r] = sum_{p in row r} cp[p] z[col p],   grow_neg[sigma(r)] = sum_{p in row r} cn[p] z[col p].
+ * Handing them to ceeg_decoder_fused_bwd leaves it two gather passes instead of four. */
 size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
 int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b,
-                           float* coef_pos, float* coef_neg, float* sums,
-                           void* ws, size_t ws_bytes, void* stream);
+                           float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
+                           float* sums, void* ws, size_t ws_bytes, void* stream);
 /* Backward of the fused decoder: dz[n] = gp * (pos terms) + gn * (neg terms) where gp/gn are read from
  * the device (gscale[0], gscale[1]: upstream grad times 1/E_pos resp. 1/n_valid_neg).
  *   dz[n] = sum_{p in row n} gp*cp[p] z[col p]                 (n as dst of positives)
  *         + sum_{q in trow n} gp*cp[tperm q] z[tcol q]         (n as src of positives)
  *         + sum_{p in row sigma^-1(n)} gn*cn[p] z[col p]       (n as negative endpoint sigma(r))
  *         + sum_{q in trow n} gn*cn[tperm q] z[sigma(tcol q)]  (n as src of negatives)
- * sig_ainv = a^-1 mod N. */
+ * sig_ainv = a^-1 mod N.  With grow_pos/grow_neg from the forward (both non-NULL) the first and third sums are
+ * taken from those tables and only the two transposed passes run; with NULL all four passes run. */
 int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                            const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
-                           const float* coef_pos, const float* coef_neg, const float* gscale,
+                           const float* coef_pos, const float* coef_neg, const float* grow_pos,
+                           const float* grow_neg, int64_t ldg, const float* gscale,
                            float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                            void* ws, size_t ws_bytes, void* stream);
+
+/* Streaming helpers around the dense transform of a GCN layer (no counterpart of their own in the reference:
+ * they stand where its host code calls torch.relu / autograd's ReLU backward / the bias-gradient reduction).
+ *   ceeg_bias_relu       : y[n,:] = act(y[n,:] + bias) in place; bias may be NULL, relu != 0 applies max(.,0)
+ *   ceeg_relu_bwd_colsum : gm = g * (y > 0) (gm may alias g) and colsum[f] = sum_n gm[n,f], one pass
+ *   ceeg_colsum          : colsum[f] = sum_n g[n,f]   (deterministic: fixed-order block partials, fp64 finish)
+ * y, g: [N, ld] fp32 row-major, F % 4 == 0, F <= 1024, ld % 4 == 0, 16-byte aligned. */
+int ceeg_bias_relu(float* y, int64_t ld, int64_t N, int F, const float* bias, int relu, void* stream);
+size_t ceeg_colsum_ws_bytes(int64_t N, int F);
+int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F,
+                         float* colsum, void* ws, size_t ws_bytes, void* stream);
+int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, void* ws, size_t ws_bytes, void* stream);
 
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected

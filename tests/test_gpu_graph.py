@@ -109,3 +109,38 @@ def test_philox_eps_matches_oracle():
     eps = c_oracle.philox_normal(4242, N * D).reshape(N, D)
     np.testing.assert_allclose(z.cpu().numpy(), eps, rtol=2e-4, atol=2e-5)
     assert abs(kl.item()) < 1e-6
+
+
+@pytest.mark.parametrize("N,F,ld", [(1, 4, 4), (777, 32, 32), (5000, 64, 128), (100_003, 256, 256), (300_001, 128, 128)])
+def test_bias_relu_and_column_sums(N, F, ld):
+    """Streaming helpers of a GCN layer (include/ceeg.h: ceeg_bias_relu / ceeg_relu_bwd_colsum / ceeg_colsum) against
+    torch: the elementwise parts bit-exact, the column sums within fp32 summation error of an fp64 sum, and
+    identical between two runs (fixed-order reduction)."""
+    from causal_eeg_vae_amd import _lib
+    from causal_eeg_vae_amd.models import _colsum, _relu_bwd_colsum
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device="cpu").manual_seed(N + F)
+    ybuf = torch.randn(N, ld, generator=gen).to(dev)
+    y = ybuf[:, :F]
+    bias = torch.randn(F, generator=gen).to(dev)
+    want = torch.relu(y + bias)
+    got = ybuf.clone()
+    _lib.check(L.ceeg_bias_relu(got.data_ptr(), ld, N, F, bias.data_ptr(), 1, _lib.stream()), "ceeg_bias_relu")
+    torch.cuda.synchronize()
+    assert torch.equal(got[:, :F], want)
+    if ld > F:
+        assert torch.equal(got[:, F:], ybuf[:, F:])  # padding columns untouched
+
+    g = torch.randn(N, F, generator=gen).to(dev)
+    gm, cs = _relu_bwd_colsum(g, want)
+    gm2, cs2 = _relu_bwd_colsum(g, want)
+    ref = g * (want > 0)
+    assert torch.equal(gm, ref)
+    assert torch.equal(cs, cs2)
+    ref64 = ref.double().sum(0)
+    scale = ref.abs().double().sum(0) + 1e-30
+    assert float(((cs.double() - ref64).abs() / scale).max()) < 1e-6
+    cs3 = _colsum(g)
+    assert torch.equal(cs3, _colsum(g))
+    assert float(((cs3.double() - g.double().sum(0)).abs() / (g.abs().double().sum(0) + 1e-30)).max()) < 1e-6

@@ -74,7 +74,8 @@ def test_edge_bce_and_recon_loss(D):
     _close(p, ref_torch.decode(z0, ei), rtol=1e-5, atol_rel=1e-6)
 
 
-@pytest.mark.parametrize("N,E,D", [(3000, 50000, 128), (500, 20000, 32)])
+@pytest.mark.parametrize("N,E,D", [(3000, 50000, 128), (500, 20000, 32), (2000, 3000, 256), (700, 30000, 64), (900, 9000, 4),
+                                   (1500, 40000, 8), (1200, 20000, 16), (1000, 150000, 100)])
 def test_fused_decoder_vs_oracle(N, E, D):
     from causal_eeg_vae_amd import EventGraph, sigma_params
     from causal_eeg_vae_amd.models import _FusedDecoder
@@ -101,6 +102,12 @@ def test_fused_decoder_vs_oracle(N, E, D):
     _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
     rec2, _ = _FusedDecoder.apply(b, g, a_, b_, ainv)
     assert torch.equal(rec, rec2)
+    # the four-pass backward (no row-side sums kept by the forward) gives the same gradient
+    c = z0.clone().cuda().requires_grad_(True)
+    rec3, _ = _FusedDecoder.apply(c, g, a_, b_, ainv, False)
+    (rec3 * 1.7).backward()
+    assert torch.equal(rec3, rec)
+    _close(c.grad, b.grad, rtol=1e-4, atol_rel=1e-5)
 
 
 def test_gcnconv_fwd_bwd_and_state_dict():
