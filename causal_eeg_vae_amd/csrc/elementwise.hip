@@ -64,12 +64,21 @@ __global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const float* g, int6
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int F, float* __restrict__ out) {
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  if (f >= F) return;
+// 16 columns per block; 16 groups of threads walk the block partials in a fixed interleave, fp64, then a fixed-order
+// LDS sum over the 16 groups.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int F, float* __restrict__ out) {
+  __shared__ double red[256];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + c;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * F + f];
-  out[f] = (float)s;
+  if (f < F)
+    for (int b = grp; b < nblk; b += 16) s += (double)part[(size_t)b * F + f];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (grp == 0 && f < F) {
+    for (int k = 1; k < 16; ++k) s += red[k * 16 + c];
+    out[f] = (float)s;
+  }
 }
 
 int ew_blocks(int64_t work) {
@@ -94,7 +103,7 @@ int colsum_launch(const float* g, int64_t ldg, const float* y, int64_t ldy, floa
   else
     hipLaunchKernelGGL(colsum_kernel<false>, dim3((unsigned)nblk), dim3(EW_THREADS), EW_THREADS * 16, st, g, ldg, y, ldy, gm, ldm, N, F, rows_per, part);
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((F + 255) / 256), dim3(256), 0, st, part, (int)nblk, F, colsum);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((F + 15) / 16), dim3(256), 0, st, part, (int)nblk, F, colsum);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

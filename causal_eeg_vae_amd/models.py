@@ -12,6 +12,7 @@ stream, autograd bookkeeping and the dense feature transforms x @ W^T (hipBLASLt
 "plain library GEMMs").  There is no CPU fallback.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -187,11 +188,15 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
         wt = weight.t().contiguous()  # [in, out]; out*in floats
-        y = torch.mm(x, wt) if bias is None else torch.addmm(bias, x, wt)
+        if relu and bias is not None and os.environ.get("CEEG_GEMM_EPILOGUE", "1") == "1":
+            y = torch._addmm_activation(bias, x, wt)  # hipBLASLt bias+ReLU epilogue: no extra pass over [N, out]
+        else:
+            y = torch.mm(x, wt) if bias is None else torch.addmm(bias, x, wt)
+            if relu:
+                L = _lib.lib()
+                with _lib.timed("bias_relu"):
+                    _lib.check(L.ceeg_bias_relu(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], None, 1, _lib.stream()), "ceeg_bias_relu")
         if relu:
-            L = _lib.lib()
-            with _lib.timed("bias_relu"):
-                _lib.check(L.ceeg_bias_relu(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], None, 1, _lib.stream()), "ceeg_bias_relu")
             ctx.save_for_backward(x, weight, y)
         else:
             ctx.save_for_backward(x, weight)
