@@ -211,46 +211,110 @@ __device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t l
   }
 }
 
+// first row r in [0, N] with rowptr[r] >= target
+__device__ __forceinline__ int64_t dec_row_lower_bound(const int32_t* __restrict__ rowptr, int64_t N, int64_t target) {
+  int64_t lo = 0, hi = N;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] < target) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+constexpr int DEC_ROWS = 16;          // consecutive rows a wave draws at a time
+constexpr int DEC_BLOCKS_PER_XCD = 256;
+constexpr size_t DEC_QUEUE_BYTES = 8 * 128;
+
+struct DecRow {     // everything a row needs before its gathers, fetched one row ahead
+  int p_lo, p_hi, s_lo, s_hi, sr;
+  int bc, sc;       // lane's entry of the row's first 64 columns / of row sigma(r)'s first 64 columns
+  float4 zr, zs;
+};
+
 // Row r of the dst-sorted CSR: positives (r, col p), negatives (col p, sigma(r)) - both share the gather of z[col p].
 // GRAD also leaves the row-side gradient sums (unscaled):  grow_pos[r] = sum_p cp[p] z[col p],
 // grow_neg[sigma(r)] = sum_p cn[p] z[col p]  (sigma is a bijection: every row of both tables is written once).
+//
+// Scheduling (as spmm.hip): persistent grid, the workgroups sharing blockIdx%8 (one XCD, one L2) own a contiguous,
+// nonzero-balanced range of rows and sweep it in order - every WAVE draws DEC_ROWS consecutive rows from the XCD's
+// counter (next draw in flight while the current rows are processed; the counter only grows, so every wave leaves
+// once its draw passes the end).  Per draw, the row pointers of the DEC_ROWS rows and of their sigma-rows come in
+// one lane-parallel load; per row, the column batch, sigma(r)'s column batch and the two fixed latent rows are
+// fetched one row ahead, so a row costs ~one gather latency instead of the
+// rowptr -> col -> binary search -> gather chain.  The collision test (is col p -> sigma(r) an edge?) compares
+// against sigma(r)'s columns held across the lanes (memory binary search only for sigma-rows longer than 64).
 template <int LPR, bool GRAD>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int D,
     int64_t sig_a, int64_t sig_b, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
-    float* __restrict__ grow_neg, int64_t ldg, float* __restrict__ part) {
-  __shared__ float red[3 * DEC_WAVES];
+    float* __restrict__ grow_neg, int64_t ldg, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed */,
+    float* __restrict__ part) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int fl = lane % LPR;
   const bool fl_ok = 4 * fl < D;
-  const int64_t wave = (int64_t)blockIdx.x * DEC_WAVES + (threadIdx.x >> 6);
-  const int64_t nwaves = (int64_t)gridDim.x * DEC_WAVES;
+  const int xcd = blockIdx.x & 7;
+  const int64_t nnz = rowptr[N];
+  const int64_t r_begin = xcd == 0 ? 0 : dec_row_lower_bound(rowptr, N, nnz * xcd / 8);
+  const int64_t r_end = xcd == 7 ? N : dec_row_lower_bound(rowptr, N, nnz * (xcd + 1) / 8);
+  unsigned int* q = queue + xcd * 32;
   DecRowState st;
-  st.s_pos = st.s_neg = st.s_cnt = 0.f;
-  // contiguous slab of rows per wave: neighbouring rows (time-local events) stay on one CU / XCD
-  const int64_t per = (N + nwaves - 1) / nwaves;
-  const int64_t r_lo = wave * per, r_hi = r_lo + per < N ? r_lo + per : N;
-  for (int64_t r = r_lo; r < r_hi; ++r) {
-    const int p_lo = rowptr[r], p_hi = rowptr[r + 1];
-    const int64_t sr = (int64_t)(((uint64_t)sig_a * (uint64_t)r + (uint64_t)sig_b) % (uint64_t)N);
-    st.ga = make_float4(0.f, 0.f, 0.f, 0.f);
-    st.gb = st.ga;
-    if (p_lo != p_hi) {
-      st.zr = st.ga;
-      st.zs = st.ga;
-      if (fl_ok) {
-        st.zr = *reinterpret_cast<const float4*>(z + r * ldz + 4 * fl);
-        st.zs = *reinterpret_cast<const float4*>(z + sr * ldz + 4 * fl);
-      }
-      const int s_lo = rowptr[sr], s_hi = rowptr[sr + 1];
-      for (int base = p_lo; base < p_hi; base += 64) {
-        const int n = p_hi - base < 64 ? p_hi - base : 64;
-        int my_c = 0, my_valid = 0;
-        if (lane < n) {
-          my_c = col[base + lane];
-          my_valid = (my_c != (int)sr && !sorted_has(col, s_lo, s_hi, my_c)) ? 1 : 0;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  unsigned int dv = 0;
+  if (lane == 0) dv = atomicAdd(q, (unsigned)DEC_ROWS);
+  for (;;) {
+    const int64_t base_r = r_begin + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
+    if (base_r >= r_end) break;
+    if (lane == 0) dv = atomicAdd(q, (unsigned)DEC_ROWS);  // the next draw lands while these rows run
+    const int cnt = r_end - base_r < DEC_ROWS ? (int)(r_end - base_r) : DEC_ROWS;
+    st.s_pos = st.s_neg = st.s_cnt = 0.f;
+    int rp = 0, sri = 0, sp_lo = 0, sp_hi = 0;
+    if (lane <= cnt) rp = rowptr[base_r + lane];
+    if (lane < cnt) {
+      sri = (int)(((uint64_t)sig_a * (uint64_t)(base_r + lane) + (uint64_t)sig_b) % (uint64_t)N);
+      sp_lo = rowptr[sri];
+      sp_hi = rowptr[sri + 1];
+    }
+    auto fetch = [&](int i) -> DecRow {
+      DecRow w;
+      w.p_lo = __builtin_amdgcn_readlane(rp, i);
+      w.p_hi = __builtin_amdgcn_readlane(rp, i + 1);
+      w.s_lo = __builtin_amdgcn_readlane(sp_lo, i);
+      w.s_hi = __builtin_amdgcn_readlane(sp_hi, i);
+      w.sr = __builtin_amdgcn_readlane(sri, i);
+      w.bc = 0; w.sc = 0; w.zr = zero4; w.zs = zero4;
+      if (w.p_lo != w.p_hi) {
+        if (lane < w.p_hi - w.p_lo) w.bc = col[w.p_lo + lane];
+        if (lane < w.s_hi - w.s_lo) w.sc = col[w.s_lo + lane];
+        if (fl_ok) {
+          w.zr = *reinterpret_cast<const float4*>(z + (base_r + i) * ldz + 4 * fl);
+          w.zs = *reinterpret_cast<const float4*>(z + (int64_t)w.sr * ldz + 4 * fl);
         }
+      }
+      return w;
+    };
+    DecRow cur = fetch(0);
+    for (int i = 0; i < cnt; ++i) {
+      DecRow nxt = cur;
+      if (i + 1 < cnt) nxt = fetch(i + 1);
+      const int64_t r = base_r + i;
+      st.ga = zero4;
+      st.gb = zero4;
+      st.zr = cur.zr;
+      st.zs = cur.zs;
+      const int s_n = cur.s_hi - cur.s_lo;
+      for (int base = cur.p_lo; base < cur.p_hi; base += 64) {
+        const int n = cur.p_hi - base < 64 ? cur.p_hi - base : 64;
+        int my_c = cur.bc;
+        if (base != cur.p_lo) my_c = lane < n ? col[base + lane] : 0;
+        bool hit = false;
+        if (s_n <= 64) {
+          for (int t = 0; t < s_n; ++t) hit |= (my_c == __builtin_amdgcn_readlane(cur.sc, t));
+        } else if (lane < n) {
+          hit = sorted_has(col, cur.s_lo, cur.s_hi, my_c);
+        }
+        const int my_valid = (lane < n && my_c != cur.sr && !hit) ? 1 : 0;
         const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
         int i0 = 0;
         for (; i0 + 8 <= ns; i0 += 8) dec_round<LPR, 8, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
@@ -260,24 +324,31 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
         else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
         else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
       }
-    }
-    if constexpr (GRAD) {
-      if constexpr (G > 1) {
+      if constexpr (GRAD) {
+        if constexpr (G > 1) {
 #pragma unroll
-        for (int o = 32; o >= LPR; o >>= 1) {
-          st.ga.x += __shfl_xor(st.ga.x, o, 64); st.ga.y += __shfl_xor(st.ga.y, o, 64);
-          st.ga.z += __shfl_xor(st.ga.z, o, 64); st.ga.w += __shfl_xor(st.ga.w, o, 64);
-          st.gb.x += __shfl_xor(st.gb.x, o, 64); st.gb.y += __shfl_xor(st.gb.y, o, 64);
-          st.gb.z += __shfl_xor(st.gb.z, o, 64); st.gb.w += __shfl_xor(st.gb.w, o, 64);
+          for (int o = 32; o >= LPR; o >>= 1) {
+            st.ga.x += __shfl_xor(st.ga.x, o, 64); st.ga.y += __shfl_xor(st.ga.y, o, 64);
+            st.ga.z += __shfl_xor(st.ga.z, o, 64); st.ga.w += __shfl_xor(st.ga.w, o, 64);
+            st.gb.x += __shfl_xor(st.gb.x, o, 64); st.gb.y += __shfl_xor(st.gb.y, o, 64);
+            st.gb.z += __shfl_xor(st.gb.z, o, 64); st.gb.w += __shfl_xor(st.gb.w, o, 64);
+          }
+        }
+        if (lane < LPR && fl_ok) {
+          *reinterpret_cast<float4*>(grow_pos + r * ldg + 4 * fl) = st.ga;
+          *reinterpret_cast<float4*>(grow_neg + (int64_t)cur.sr * ldg + 4 * fl) = st.gb;
         }
       }
-      if (lane < LPR && fl_ok) {
-        *reinterpret_cast<float4*>(grow_pos + r * ldg + 4 * fl) = st.ga;
-        *reinterpret_cast<float4*>(grow_neg + sr * ldg + 4 * fl) = st.gb;
-      }
+      cur = nxt;
+    }
+    // loss partials per DRAW, not per wave: which wave ran a draw must not change the sums.  Slots are unique:
+    // draws of one XCD are DEC_ROWS apart, and the +xcd keeps neighbouring ranges from sharing a slot.
+    const float t0 = ceeg_wave_sum(st.s_pos), t1 = ceeg_wave_sum(st.s_neg), t2 = ceeg_wave_sum(st.s_cnt);
+    if (lane == 0) {
+      float* o = part + (size_t)(base_r / DEC_ROWS + xcd) * 3;
+      o[0] = t0; o[1] = t1; o[2] = t2;
     }
   }
-  dec_block_out(st.s_pos, st.s_neg, st.s_cnt, red, part);
 }
 
 int dec_lpr(int D) {
@@ -331,9 +402,10 @@ extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, 
 
 extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
   if (N <= 0 || nnz < 0 || D <= 0) return 0;
-  const size_t a = ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
+  const size_t a = DEC_QUEUE_BYTES + ceeg_ws_part((size_t)(N / DEC_ROWS + 16) * 3, 4);
+  const size_t a0 = ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
   const size_t b = ceeg_spmm_ws_bytes(N, nnz, D);
-  return a > b ? a : b;
+  return (a > b ? a : b) > a0 ? (a > b ? a : b) : a0;
 }
 
 extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
@@ -349,18 +421,22 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   if (ws_bytes < ceeg_decoder_fused_ws_bytes(N, nnz, D) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* part = static_cast<float*>(ws);
+  unsigned int* queue = static_cast<unsigned int*>(ws);  // queue counters, then one loss-partial slot per draw (unused slots stay 0)
+  part = reinterpret_cast<float*>(static_cast<char*>(ws) + DEC_QUEUE_BYTES);
+  const int nslots = (int)(N / DEC_ROWS + 16);
+  if (hipMemsetAsync(ws, 0, DEC_QUEUE_BYTES + (size_t)nslots * 3 * 4, st) != hipSuccess) return CEEG_ELAUNCH;
   const int lpr = dec_lpr(D);
-  int64_t nb = (N + DEC_WAVES * 4 - 1) / (DEC_WAVES * 4);  // ~4 rows per wave at least
-  if (nb < 1) nb = 1;
-  const int nblk = (int)(nb < DEC_MAX_BLOCKS ? nb : DEC_MAX_BLOCKS);
+  int64_t per_xcd = (N + 8 * DEC_WAVES * DEC_ROWS - 1) / (8 * DEC_WAVES * DEC_ROWS);  // enough blocks for one draw per wave ...
+  if (per_xcd > DEC_BLOCKS_PER_XCD) per_xcd = DEC_BLOCKS_PER_XCD;                     // ... capped at a persistent grid
+  const int nblk = (int)(8 * per_xcd);
 #define CEEG_DEC_CASE(L)                                                                                                              \
   case L:                                                                                                                             \
     if (grow_pos)                                                                                                                     \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
-                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, part);                                                   \
+                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     else                                                                                                                              \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
-                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, part);                                                   \
+                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     break;
   switch (lpr) {
     CEEG_DEC_CASE(1)
@@ -374,7 +450,7 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   }
 #undef CEEG_DEC_CASE
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, 3, sums);
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(256), 0, st, part, nslots, 3, sums);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
