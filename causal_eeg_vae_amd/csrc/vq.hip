@@ -543,6 +543,28 @@ __global__ void vq_dz_kernel(const void* __restrict__ z, const float* __restrict
   }
 }
 
+// fp32, D % 4 == 0, 16-byte aligned operands: one float4 per lane (same arithmetic per element as above)
+__global__ __launch_bounds__(256) void vq_dz4_kernel(const float* __restrict__ z, const float* __restrict__ W, const int64_t* __restrict__ idx,
+                                                     const float* __restrict__ g, const float* __restrict__ s_dev, int64_t B, int D,
+                                                     float* __restrict__ dz) {
+  const float coef = s_dev[0] * (2.0f / ((float)B * (float)D));
+  const int dq = D / 4;
+  const int64_t total = B * dq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t b = i / dq;
+    const int k = (int)(i - b * dq) * 4;
+    const float4 zv = *reinterpret_cast<const float4*>(z + b * D + k);
+    const float4 w = *reinterpret_cast<const float4*>(W + (size_t)idx[b] * D + k);
+    float4 v;
+    v.x = coef * (zv.x - w.x); v.y = coef * (zv.y - w.y); v.z = coef * (zv.z - w.z); v.w = coef * (zv.w - w.w);
+    if (g) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + b * D + k);
+      v.x += gv.x; v.y += gv.y; v.z += gv.z; v.w += gv.w;
+    }
+    *reinterpret_cast<float4*>(dz + b * D + k) = v;
+  }
+}
+
 // scan of the per-slice histograms: off[g][c] = (rows with smaller code) + (rows with code c in slices < g);
 // also the per-code chunk table for the segmented sum.  One block.
 __global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, int n_e, uint32_t* __restrict__ off,
@@ -551,6 +573,7 @@ __global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, i
   uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
   for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
     uint32_t t = 0;
+#pragma unroll 8
     for (int g = 0; g < nslice; ++g) t += hpart[(size_t)g * n_e + c];
     tot[c] = t;
   }
@@ -569,6 +592,7 @@ __global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, i
   __syncthreads();
   for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
     uint32_t run = code_base[c];
+#pragma unroll 8
     for (int g = 0; g < nslice; ++g) {
       off[(size_t)g * n_e + c] = run;
       run += hpart[(size_t)g * n_e + c];
@@ -576,9 +600,10 @@ __global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, i
   }
 }
 
-// stable scatter: one wave per slice walks its rows in order, 64 at a time; equal codes inside a batch are
-// ranked by lane order -> sorted[] lists the rows of each code in ascending row order (deterministic).
-__global__ __launch_bounds__(64) void vq_scatter_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int64_t rows_per,
+// stable scatter: one wave per slice walks its rows in order, 64 at a time.  The lanes holding the same code find
+// each other with one ballot per code bit (no loop over the distinct codes of the batch); equal codes are ranked
+// by lane order -> sorted[] lists the rows of each code in ascending row order (deterministic).
+__global__ __launch_bounds__(64) void vq_scatter_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int nbits, int64_t rows_per,
                                                         const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [n_e]
@@ -587,27 +612,32 @@ __global__ __launch_bounds__(64) void vq_scatter_kernel(const int64_t* __restric
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per;
   const int64_t hi = lo + rows_per < B ? lo + rows_per : B;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  int64_t k_next = lo + lane < hi ? idx[lo + lane] : -1;
   for (int64_t b0 = lo; b0 < hi; b0 += 64) {
     const int64_t b = b0 + lane;
-    const bool valid = b < hi;
-    int k = valid ? (int)idx[b] : -1;
-    if (k < 0 || k >= n_e) k = -1;
-    unsigned long long rem = __ballot(k >= 0);
-    while (rem) {
-      const int leader = __ffsll((long long)rem) - 1;
-      const int k0 = __shfl(k, leader, 64);
-      const unsigned long long m = __ballot(k == k0);
-      const uint32_t base = cur[k0];
-      if (k == k0) sorted[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)b;
-      __syncthreads();  // single-wave block: orders the LDS read above before the update below
-      if (lane == leader) cur[k0] = base + (uint32_t)__popcll(m);
-      __syncthreads();
-      rem &= ~m;
+    int k = (int)k_next;
+    if (k_next < 0 || k_next >= n_e) k = -1;
+    k_next = b + 64 < hi ? idx[b + 64] : -1;  // next batch in flight
+    unsigned long long peers = __ballot(k >= 0);
+    for (int bit = 0; bit < nbits; ++bit) {
+      const bool one = (k >> bit) & 1;
+      const unsigned long long m = __ballot(one);
+      peers &= one ? m : ~m;
     }
+    if (k >= 0) {
+      const uint32_t base = cur[k];
+      sorted[base + (uint32_t)__popcll(peers & below)] = (uint32_t)b;
+    }
+    __syncthreads();  // single-wave block: every lane has read cur[] before the leaders advance it
+    if (k >= 0 && (peers & below) == 0) cur[k] += (uint32_t)__popcll(peers);
+    __syncthreads();
   }
 }
 
 // segmented sum: one wave per (code, chunk of <= VQ_SEG sorted rows); rows are added in list order.
+// Lane l owns elements l, l+64, ... of the row (D <= 256: up to 4); the chunk's row ids arrive 64 at a time in one
+// lane-parallel load and are broadcast from there, 8 rows' loads in flight.
 template <bool BF16>
 __global__ __launch_bounds__(256) void vq_segsum_kernel(const void* __restrict__ z, const uint32_t* __restrict__ sorted,
                                                         const uint32_t* __restrict__ code_base, const uint32_t* __restrict__ chunk_base,
@@ -623,11 +653,31 @@ __global__ __launch_bounds__(256) void vq_segsum_kernel(const void* __restrict__
   const int c = lo;
   const uint32_t p0 = code_base[c] + (w - chunk_base[c]) * VQ_SEG;
   const uint32_t p1 = p0 + VQ_SEG < code_base[c + 1] ? p0 + VQ_SEG : code_base[c + 1];
-  for (int k = lane; k < D; k += 64) {
-    float acc = 0.f;
-    for (uint32_t p = p0; p < p1; ++p) acc += vq_ld<BF16>(z, (size_t)sorted[p] * D + k);
-    partial[(size_t)w * D + k] = acc;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (uint32_t pb = p0; pb < p1; pb += 64) {
+    const int n = (int)(p1 - pb < 64u ? p1 - pb : 64u);
+    const int my = lane < n ? (int)sorted[pb + lane] : 0;
+    for (int j0 = 0; j0 < n; j0 += 8) {
+      float v[8][4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = j0 + u < n ? j0 + u : n - 1;  // wave-uniform; the tail re-reads the last row and adds nothing
+        const size_t row = (size_t)(uint32_t)__builtin_amdgcn_readlane(my, j) * D;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[u][t] = (lane + 64 * t < D) ? vq_ld<BF16>(z, row + lane + 64 * t) : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (j0 + u < n) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] += v[u][t];
+        }
+      }
+    }
   }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (lane + 64 * t < D) partial[(size_t)w * D + lane + 64 * t] = acc[t];
 }
 
 // dW[c] = s*beta*(2/M) * (count_c * W[c] - sum of the code's chunk partials, in chunk order)
@@ -801,13 +851,16 @@ extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* id
                                 void* ws, size_t ws_bytes, void* stream) {
   if (!z || !W || !idx || !s_dev || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
   if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
-  if (n_e > 16384 || B >= ((int64_t)1 << 32)) return CEEG_EUNSUPPORTED;
+  if (D > 256 || n_e > 16384 || B >= ((int64_t)1 << 32)) return CEEG_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (dz) {
     const int64_t total = B * D;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dtype == CEEG_BF16)
       hipLaunchKernelGGL(vq_dz_kernel<true>, dim3(blocks), dim3(256), 0, st, z, W, idx, g, s_dev, B, D, dz);
+    else if ((D % 4) == 0 && ceeg_aligned(z, 16) && ceeg_aligned(W, 16) && ceeg_aligned(dz, 16) && (!g || ceeg_aligned(g, 16)))
+      hipLaunchKernelGGL(vq_dz4_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(z), W, idx, static_cast<const float*>(g),
+                         s_dev, B, D, static_cast<float*>(dz));
     else
       hipLaunchKernelGGL(vq_dz_kernel<false>, dim3(blocks), dim3(256), 0, st, z, W, idx, g, s_dev, B, D, dz);
     CEEG_CHECK_LAUNCH();
@@ -821,7 +874,9 @@ extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* id
     CEEG_CHECK_LAUNCH();
     hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(512), (size_t)n_e * 4, st, w.hpart, nslice, n_e, w.off, w.code_base, w.chunk_base);
     CEEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_scatter_kernel, dim3(nslice), dim3(64), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.off, w.sorted);
+    int nbits = 0;
+    while ((1 << nbits) < n_e) ++nbits;
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(nslice), dim3(64), (size_t)n_e * 4, st, idx, B, n_e, nbits, (int64_t)VQ_HIST_ROWS, w.off, w.sorted);
     CEEG_CHECK_LAUNCH();
     const int64_t nchunk_max = B / VQ_SEG + n_e + 1;
     const unsigned sblocks = (unsigned)((nchunk_max + 3) / 4);
