@@ -10,7 +10,8 @@ optimizer step (encode -> reparam+KL -> VQ -> decode with 1:1 negatives -> backw
 with every input already resident in HBM.  value = positive directed edges processed per second, whole job.
 Multi-GPU: one graph shard per rank (weak scaling), gradients averaged with one RCCL all-reduce per step.
 
-Extra (my own measurements, not the driver's contract): --workload vq  (BASELINE.json configs[2]).
+Extra (my own measurements, not the driver's contract): --workload vq (BASELINE.json configs[2]) and
+--workload cvgae (configs[3]: conditional VGAE + VQ on 64 collated graphs x 100k edges per rank).
 """
 import argparse
 import json
@@ -36,7 +37,11 @@ def parse():
     ap.add_argument("--in-dim", type=int, default=128)
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--codes", type=int, default=512)
-    ap.add_argument("--workload", default="vgae", choices=["vgae", "vq"])
+    ap.add_argument("--workload", default="vgae", choices=["vgae", "vq", "cvgae"])
+    ap.add_argument("--graphs", type=int, default=64)           # cvgae (configs[3]): graphs per rank
+    ap.add_argument("--edges-per-graph", type=int, default=100_000)
+    ap.add_argument("--nodes-per-graph", type=int, default=6_250)
+    ap.add_argument("--cond-dim", type=int, default=32)
     ap.add_argument("--vq-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
@@ -121,6 +126,44 @@ def main():
                           "config": {"workload": f"VectorQuantizer fwd {B}x{n_e}x{D}"},
                           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                        "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None}}))
+        return
+
+    if args.workload == "cvgae":
+        from causal_eeg_vae_amd import ConditionalVGAEVQ
+        from causal_eeg_vae_amd.synth import collate_graphs
+        G, n, e, C = args.graphs, args.nodes_per_graph, args.edges_per_graph, args.cond_dim
+        eis = [synth_event_graph(n, e, seed=(1000 + rank) * 4096 + g, device=dev) for g in range(G)]
+        ei, batch, N = collate_graphs(eis, [n] * G)
+        x = synth_features(N, args.in_dim, seed=1000 + rank, device=dev)
+        gen = torch.Generator(device=dev).manual_seed(77 + rank)
+        cond = torch.randn(G, C, generator=gen, device=dev)
+        graph = EventGraph(ei, N)
+        graph.dec
+        torch.manual_seed(0)
+        model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
+        with torch.no_grad():
+            model.vector_quantization.embedding.weight.normal_(0, 0.1)
+        trainer = Trainer(model, lr=1e-3, world_size=world)
+        for _ in range(args.warmup):
+            trainer.step(x, graph, batch, cond, nodes_per_graph=n)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss, aux = trainer.step(x, graph, batch, cond, nodes_per_graph=n)
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        if rank == 0:
+            print(json.dumps({"metric": "VGAE train edges/sec", "value": G * e * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": f"conditional GCN-VGAE+VQ train step, {G} collated graphs x {e} edges x {n} nodes per GPU, "
+                                                     f"in {args.in_dim}+{C}, latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 negatives, Adam",
+                                         "parallelism": f"dp{world}"}, "loss": float(loss.item())}))
+        if world > 1:
+            dist.destroy_process_group()
         return
 
     N, E = args.nodes, args.edges

@@ -81,8 +81,14 @@ __device__ __forceinline__ float2 ceeg_box_muller(uint32_t x0, uint32_t x1) {
 // ---------------------------------------------------------------- internal cross-file launchers
 // Extra addressing for the SpMM used by the fused decoder backward: affine (bijective) maps on the
 // gathered column index and on the output row, and a device-side scale applied to the row sum.
+// sigma(x) = (x - x % mod) + (a * (x % mod) + b) % mod: an affine permutation inside every block of `mod` consecutive ids
+// (mod = N: one permutation of all nodes; mod = nodes per graph: negatives stay inside their graph of a collated batch)
+__host__ __device__ __forceinline__ int64_t ceeg_block_affine(int64_t x, int64_t a, int64_t b, int64_t mod) {
+  const uint64_t l = (uint64_t)x % (uint64_t)mod;
+  return x - (int64_t)l + (int64_t)(((uint64_t)a * l + (uint64_t)b) % (uint64_t)mod);
+}
 struct CeegSpmmEx {
-  int64_t row_a = 1, row_b = 0, col_a = 1, col_b = 0, mod = 1;
+  int64_t row_a = 1, row_b = 0, col_a = 1, col_b = 0, mod = 1;  // id maps through ceeg_block_affine
   int64_t max_row_nnz = -1;  // longest row if the caller knows it (<0: unknown -> the long-row pass always runs)
   const float* scale = nullptr;
   const float* addend = nullptr;  // [N, ld_add]: added to row r's sum before the scale (row index BEFORE the row map)

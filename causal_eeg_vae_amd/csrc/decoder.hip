@@ -246,7 +246,7 @@ struct DecRow {     // everything a row needs before its gathers, fetched one ro
 template <int LPR, bool GRAD>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int D,
-    int64_t sig_a, int64_t sig_b, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
+    int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
     float* __restrict__ grow_neg, int64_t ldg, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed */,
     float* __restrict__ part) {
   constexpr int G = 64 / LPR;
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     int rp = 0, sri = 0, sp_lo = 0, sp_hi = 0;
     if (lane <= cnt) rp = rowptr[base_r + lane];
     if (lane < cnt) {
-      sri = (int)(((uint64_t)sig_a * (uint64_t)(base_r + lane) + (uint64_t)sig_b) % (uint64_t)N);
+      sri = (int)ceeg_block_affine(base_r + lane, sig_a, sig_b, sig_mod);
       sp_lo = rowptr[sri];
       sp_hi = rowptr[sri + 1];
     }
@@ -409,14 +409,14 @@ extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
 }
 
 extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
-                                      int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b,
+                                      int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                                       float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
                                       float* sums, void* ws, size_t ws_bytes, void* stream) {
   if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
   if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
   if (!z || !rowptr || !sums || N <= 0 || nnz < 0 || D <= 0 || (nnz > 0 && (!col || !coef_pos || !coef_neg))) return CEEG_EINVAL;
   if ((D % 4) != 0 || D > 256 || (ldz % 4) != 0 || ldz < D || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
-  if (sig_a <= 0 || sig_a >= N + (N == 1) || sig_b < 0 || sig_b >= N) return CEEG_EINVAL;
+  if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_a >= sig_mod + (sig_mod == 1) || sig_b < 0 || sig_b >= sig_mod) return CEEG_EINVAL;
   if (!ceeg_aligned(z, 16)) return CEEG_EINVAL;
   if (ws_bytes < ceeg_decoder_fused_ws_bytes(N, nnz, D) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -433,10 +433,10 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   case L:                                                                                                                             \
     if (grow_pos)                                                                                                                     \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
-                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
+                         sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     else                                                                                                                              \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
-                         sig_b, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
+                         sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     break;
   switch (lpr) {
     CEEG_DEC_CASE(1)
@@ -457,14 +457,14 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
 
 extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                                       const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
-                                      int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                                      int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
                                       const float* coef_pos, const float* coef_neg, const float* grow_pos,
                                       const float* grow_neg, int64_t ldg, const float* gscale, float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                                       void* ws, size_t ws_bytes, void* stream) {
   if (!z || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0) return CEEG_EINVAL;
   if (nnz > 0 && (!col || !t_col || !t_perm || !coef_pos || !coef_neg)) return CEEG_EINVAL;
-  if (sig_a <= 0 || sig_b < 0 || sig_b >= N || sig_ainv <= 0) return CEEG_EINVAL;
-  if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)N) != (uint64_t)(1 % N)) return CEEG_EINVAL;
+  if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_b < 0 || sig_b >= sig_mod || sig_ainv <= 0) return CEEG_EINVAL;
+  if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)sig_mod) != (uint64_t)(1 % sig_mod)) return CEEG_EINVAL;
   if (ws_bytes < ceeg_decoder_fused_ws_bytes(N, nnz, D)) return CEEG_EWORKSPACE;
   if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
   if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
@@ -474,14 +474,14 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
     // the forward already holds the row-side sums (terms (1) and (3) below); two transposed passes finish the job:
     //   dz[n]  = gp * (grow_pos[n] + sum_{q in trow n} cp[tperm q] z[tcol q])
     //   dz[n] += gn * (grow_neg[n] + sum_{q in trow n} cn[tperm q] z[sigma(tcol q)])
-    CeegSpmmEx t2; t2.mod = N; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg;
+    CeegSpmmEx t2; t2.mod = sig_mod; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg;
     rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, t2);
     if (rc != CEEG_OK) return rc;
     CeegSpmmEx t4 = t2; t4.scale = gscale + 1; t4.col_a = sig_a; t4.col_b = sig_b; t4.addend = grow_neg;
     return ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, t4);
   }
   // (1) n as dst of positives:            dz[n]  = gp * sum_{p in row n} cp[p] z[col p]
-  CeegSpmmEx e1; e1.mod = N; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz;
+  CeegSpmmEx e1; e1.mod = sig_mod; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz;
   CeegSpmmEx e2 = e1; e2.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_pos, nullptr, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, e1);
   if (rc != CEEG_OK) return rc;
@@ -489,11 +489,11 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e2);
   if (rc != CEEG_OK) return rc;
   // (3) n = sigma(r) as negative endpoint: dz[sigma(r)] += gn * sum_{p in row r} cn[p] z[col p]
-  CeegSpmmEx e3; e3.mod = N; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz;
+  CeegSpmmEx e3; e3.mod = sig_mod; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_neg, nullptr, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e3);
   if (rc != CEEG_OK) return rc;
   // (4) n as src of negatives:            dz[n] += gn * sum_{q in trow n} cn[tperm q] z[sigma(tcol q)]
-  CeegSpmmEx e4; e4.mod = N; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz;
+  CeegSpmmEx e4; e4.mod = sig_mod; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e4);
   return rc;
 }

@@ -74,7 +74,7 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
   my_v = 0.f;
   if (base + lane < p_hi) {
     my_c = col[base + lane];
-    if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)(((uint64_t)ex.col_a * (uint64_t)my_c + (uint64_t)ex.col_b) % (uint64_t)ex.mod);
+    if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)ceeg_block_affine((int64_t)my_c, ex.col_a, ex.col_b, ex.mod);
     my_v = vperm ? val[vperm[base + lane]] : val[base + lane];
   }
 }
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
           acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
         }
         int64_t ro = r;
-        if (ex.row_a != 1 || ex.row_b != 0) ro = (int64_t)(((uint64_t)ex.row_a * (uint64_t)r + (uint64_t)ex.row_b) % (uint64_t)ex.mod);
+        if (ex.row_a != 1 || ex.row_b != 0) ro = ceeg_block_affine(r, ex.row_a, ex.row_b, ex.mod);
         float* o = out + ro * ldo + foff;
         if (accumulate) {
           const float4 t = *reinterpret_cast<const float4*>(o);

@@ -379,7 +379,9 @@ def negative_sampling(edge_index, num_nodes, num_neg_samples=None, seed=0, graph
 
 def sigma_params(num_nodes, seed, step):
     """(a, b, a^-1) of the per-step node permutation sigma(x) = (a x + b) mod N used by the fused decoder's
-    permutation-structured negatives; splitmix64 of (seed, step), a bumped until gcd(a, N) == 1."""
+    permutation-structured negatives; splitmix64 of (seed, step), a bumped until gcd(a, N) == 1.
+    For a collated batch of equal-sized graphs pass the nodes PER GRAPH as `num_nodes` and hand the same number to
+    the decoder as `sig_mod`: sigma then permutes inside every graph (include/ceeg.h, ceeg_decoder_fused_fwd)."""
     def mix(x):
         x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
@@ -400,11 +402,12 @@ class _FusedDecoder(torch.autograd.Function):
     """recon_loss with permutation-structured negatives: one gather pass for both terms (ceeg_decoder_fused_*)."""
 
     @staticmethod
-    def forward(ctx, z, graph, a, b, ainv, row_sums=True):
+    def forward(ctx, z, graph, a, b, ainv, row_sums=True, sig_mod=None):
         _lib.require_cuda(z)
         L = _lib.lib()
         z = z.contiguous()
         N, D = z.shape
+        mod = int(N if sig_mod is None else sig_mod)
         p = graph.dec
         cp = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
         cn = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
@@ -413,13 +416,13 @@ class _FusedDecoder(torch.autograd.Function):
         grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         with _lib.timed("decoder_fwd"):
-            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b,
+            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
                                                 cp.data_ptr(), cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
         ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
         ctx.save_for_backward(z, cp, cn, inv)
-        ctx.graph, ctx.sig = graph, (a, b, ainv)
+        ctx.graph, ctx.sig = graph, (a, b, ainv, mod)
         ctx.mark_non_differentiable(sums)
         return sums[0] * inv[0] + sums[1] * inv[1], sums
 
@@ -429,19 +432,19 @@ class _FusedDecoder(torch.autograd.Function):
         L = _lib.lib()
         N, D = z.shape
         p = ctx.graph.dec
-        a, b, ainv = ctx.sig
+        a, b, ainv, mod = ctx.sig
         gscale = (inv * g).contiguous()
         dz = torch.empty_like(z)
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         grow = ctx.grow
         with _lib.timed("decoder_bwd"):
             _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
-                                                p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, cp.data_ptr(),
+                                                p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, mod, cp.data_ptr(),
                                                 cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
                                                 _lib.stream()), "ceeg_decoder_fused_bwd")
         ctx.grow = None
-        return dz, None, None, None, None, None
+        return dz, None, None, None, None, None, None
 
 
 # ==================================================================================================
@@ -537,5 +540,41 @@ class VGAEVQ(nn.Module):
         vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
         a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
         rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv)
+        loss = rec + kl / N + vq_loss
+        return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
+
+
+class ConditionalVGAEVQ(nn.Module):
+    """Conditional GCN-VGAE + VQ on a PyG-style collated batch of graphs (BASELINE config 4).
+
+    The per-graph condition c [G, C] is broadcast to the nodes as c[batch] and concatenated to the encoder input
+    (scripts/models.py:162: `cat((x, condition))`) and to the latent before decoding (scripts/models.py:259:
+    `cat((latent, condition))`); `batch` is the collated graph-id vector (scripts/run.py:310-311,
+    scripts/models.py:121-122).  Everything else is the VGAEVQ step.  With `nodes_per_graph` (equal-sized graphs)
+    the permutation-structured negatives stay inside their graph; without it sigma permutes all nodes of the batch.
+    in_channels + cond_channels and latent + cond_channels must be multiples of 4 (16-byte gathers), the latter <= 256."""
+
+    def __init__(self, in_channels, cond_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0):
+        super().__init__()
+        if (in_channels + cond_channels) % 4 or (latent + cond_channels) % 4 or latent + cond_channels > 256:
+            raise ValueError("in_channels + cond_channels and latent + cond_channels must be multiples of 4 (latent + cond <= 256)")
+        self.encoder = VariationalGCNEncoder(in_channels + cond_channels, latent)
+        self.vector_quantization = VectorQuantizer(num_latent_embeddings, latent, beta, return_one_hot=False)
+        self.latent, self.cond_channels, self.seed = latent, cond_channels, int(seed)
+
+    def forward(self, x, graph, batch, condition, step=0, eps=None, sigma=None, nodes_per_graph=None):
+        N = x.shape[0]
+        if batch.shape[0] != N or condition.shape[1] != self.cond_channels:
+            raise ValueError("batch must hold one graph id per node and condition must be [num_graphs, cond_channels]")
+        cn = condition.index_select(0, batch)  # c[batch]
+        ml = self.encoder.forward_fused(torch.cat((x, cn), dim=1), graph)
+        seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
+        z, kl = _ReparamKL.apply(ml, None, eps, seed, self.training, False)
+        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        mod = N if nodes_per_graph is None else int(nodes_per_graph)
+        if N % mod:
+            raise ValueError("nodes_per_graph must divide the number of nodes of the batch")
+        a, b, ainv = sigma_params(mod, self.seed, step) if sigma is None else sigma
+        rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
         loss = rec + kl / N + vq_loss
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)

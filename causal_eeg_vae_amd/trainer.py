@@ -30,13 +30,20 @@ class Trainer:
         self.world_size = int(world_size)
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.opt = torch.optim.Adam(self.params, lr=lr)  # scripts/run.py:56
+        self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt)  # scripts/run.py:57 (defaults)
         self.step_idx = 0
         if self.world_size > 1:
             broadcast_params_(model)
 
-    def step(self, x, graph, eps=None):
+    def end_epoch(self, val_loss):
+        """scheduler.step(val_loss) once per epoch (scripts/run.py:131); every rank must pass the same value."""
+        self.sched.step(float(val_loss))
+
+    def step(self, x, graph, *model_args, eps=None, **model_kwargs):
+        """One optimizer step.  Extra positional / keyword arguments go to the model (ConditionalVGAEVQ takes
+        `batch, condition` and `nodes_per_graph=`)."""
         self.opt.zero_grad(set_to_none=True)                 # scripts/run.py:87
-        loss, aux = self.model(x, graph, step=self.step_idx, eps=eps)  # scripts/run.py:89-95
+        loss, aux = self.model(x, graph, *model_args, step=self.step_idx, eps=eps, **model_kwargs)  # scripts/run.py:89-95
         loss.backward()                                      # scripts/run.py:96
         allreduce_grads_(self.params, self.world_size)
         self.opt.step()                                      # scripts/run.py:97

@@ -158,7 +158,9 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
 
 /* Fused CSR-ordered decoder with permutation-structured negatives (the trainer's fast path):
  * for CSR row r (= dst) and entry p (src = col[p]):
- *   positive pair (col[p], r);   negative pair (col[p], sigma(r)), sigma(x) = (a*x + b) mod N, gcd(a,N)=1.
+ *   positive pair (col[p], r);   negative pair (col[p], sigma(r)),
+ *   sigma(x) = (x - x % m) + (a*(x % m) + b) % m with m = sig_mod | N, gcd(a, m) = 1: m = N permutes all nodes,
+ *   m = nodes per graph keeps the negatives of a block-diagonal batch (equal-sized graphs) inside their graph.
  *   A negative is INVALID (masked out, coef 0) when col[p]==sigma(r) or (col[p] -> sigma(r)) is an edge
  *   (binary search in row sigma(r), rows being src-sorted).
  * One gather of z[col[p]] serves both dots.  Outputs coef_pos[nnz], coef_neg[nnz] (unscaled d term/dv),
@@ -171,7 +173,7 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
  * Handing them to ceeg_decoder_fused_bwd leaves it two gather passes instead of four. */
 size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
 int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
-                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b,
+                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                            float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
                            float* sums, void* ws, size_t ws_bytes, void* stream);
 /* Backward of the fused decoder: dz[n] = gp * (pos terms) + gn * (neg terms) where gp/gn are read from
@@ -184,7 +186,7 @@ int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, c
  * taken from those tables and only the two transposed passes run; with NULL all four passes run. */
 int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
                            const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
-                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                           int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
                            const float* coef_pos, const float* coef_neg, const float* grow_pos,
                            const float* grow_neg, int64_t ldg, const float* gscale,
                            float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,

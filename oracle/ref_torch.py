@@ -190,12 +190,15 @@ def recon_loss(z, pos_edge_index, neg_edge_index):
     return pos + neg
 
 
-def sigma_negatives_np(rowptr, col, N, a, b):
+def sigma_negatives_np(rowptr, col, N, a, b, mod=None):
     """Permutation-structured negatives (ceeg_decoder_fused_fwd): for CSR (no self-loops) entry p in row r:
-    pair (col[p], sigma(r)), sigma(x) = (a x + b) mod N; invalid when equal or when col[p]->sigma(r) is an edge."""
+    pair (col[p], sigma(r)), sigma(x) = (x - x % m) + (a (x % m) + b) % m with m = mod (default N: one permutation
+    of all nodes; m = nodes per graph: inside each graph of a collated batch); invalid when equal or when
+    col[p]->sigma(r) is an edge."""
     nnz = int(rowptr[-1])
+    m = int(N if mod is None else mod)
     rows = np.repeat(np.arange(N, dtype=np.int64), np.diff(rowptr.astype(np.int64)))
-    sig = (a * rows + b) % N
+    sig = rows - rows % m + (a * (rows % m) + b) % m
     s = col[:nnz].astype(np.int64)
     edges = set(zip(s.tolist(), rows.tolist()))
     valid = np.array([(si != di) and ((si, di) not in edges) for si, di in zip(s.tolist(), sig.tolist())], dtype=bool)
@@ -225,12 +228,19 @@ class RefVGAEVQ(nn.Module):
         self.encoder = RefEncoder(f_in, latent)
         self.vector_quantization = RefVectorQuantizer(n_e, latent, beta)
 
-    def forward(self, x, edge_index, eps, neg_edge_index, neg_valid=None):
+    def forward(self, x, edge_index, eps, neg_edge_index, neg_valid=None, batch=None, condition=None):
+        """batch / condition: config 4's conditional form - the per-graph condition c[batch] is concatenated to the
+        encoder input (scripts/models.py:162) and to the latent before decoding (scripts/models.py:259)."""
+        cn = None if condition is None else condition[batch]
+        if cn is not None:
+            x = torch.cat((x, cn), dim=1)
         mu, logstd = self.encoder(x, edge_index)
         logstd = logstd.clamp(max=MAX_LOGSTD)
         z = reparametrize(mu, logstd, eps)
         kl = kl_loss(mu, logstd)
         vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        if cn is not None:
+            z_q = torch.cat((z_q, cn), dim=1)
         pos = -torch.log(decode(z_q, edge_index) + EPS).mean()
         nterm = -torch.log(1 - decode(z_q, neg_edge_index) + EPS)
         if neg_valid is not None:

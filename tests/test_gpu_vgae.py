@@ -172,3 +172,47 @@ def test_full_step_vs_oracle():
         ref_params = dict(ref.named_parameters())
         for name, p in model.named_parameters():
             _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
+
+
+@pytest.mark.parametrize("per_graph", [True, False])
+def test_conditional_batched_step_vs_oracle(per_graph):
+    """Config 4's form: 8 collated graphs, per-graph condition c[batch] concatenated to the encoder
+    input and to the latent before decoding; negatives inside each graph (block permutation) or over the whole batch."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ, EventGraph, sigma_params
+    from causal_eeg_vae_amd.synth import collate_graphs
+    from oracle import ref_torch
+    G, n, e, Fi, C, D, n_e = 8, 500, 6000, 28, 4, 12, 32
+    eis = [torch.from_numpy(_graph(n, e, 10 + g)) for g in range(G)]
+    ei, batch, N = collate_graphs(eis, [n] * G)
+    assert N == G * n and int(batch[-1]) == G - 1
+    torch.manual_seed(1)
+    ref = ref_torch.RefVGAEVQ(Fi + C, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = ConditionalVGAEVQ(Fi, C, D, n_e, 0.25).cuda()
+    model.load_state_dict(ref.state_dict())
+    x, cond, eps = torch.randn(N, Fi), torch.randn(G, C), torch.randn(N, D)
+    mod = n if per_graph else N
+    sig = sigma_params(mod, 0, 3)
+    ei_np = ei.numpy()
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, sg, valid = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1], mod)
+    if per_graph:
+        assert np.array_equal(s // n, sg // n)  # every negative pair stays inside its graph
+    neg_ei = torch.from_numpy(np.stack([s, sg]).astype(np.int64))
+    loss_ref, aux_ref = ref(x, ei, eps, neg_ei, torch.from_numpy(valid), batch=batch, condition=cond)
+    loss_ref.backward()
+    g = EventGraph(ei.cuda(), N)
+    loss, aux = model(x.cuda(), g, batch.cuda(), cond.cuda(), step=3, eps=eps.cuda(), sigma=sig, nodes_per_graph=n if per_graph else None)
+    loss.backward()
+    assert int(aux["dec_sums"][2].item()) == int(valid.sum())
+    _close(aux["z"], aux_ref["z"], rtol=1e-4, atol_rel=1e-5)
+    same = (aux["idx"].cpu() == aux_ref["idx"])
+    assert same.double().mean() > 0.999
+    for k in ("kl", "rec", "vq"):
+        _close(aux[k], aux_ref[k], rtol=1e-4)
+    _close(loss, loss_ref, rtol=1e-4)
+    if bool(same.all()):
+        ref_params = dict(ref.named_parameters())
+        for name, p in model.named_parameters():
+            _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
