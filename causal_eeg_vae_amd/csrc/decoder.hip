@@ -49,20 +49,25 @@ __device__ __forceinline__ void dec_block_out(float s0, float s1, float s2, floa
   }
 }
 
-__global__ void dec_finalize_kernel(const float* __restrict__ part, int nblk, int nout, float* __restrict__ out) {
-  __shared__ double red[256];
-  for (int k = 0; k < nout; ++k) {
-    double s = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += 256) s += (double)part[(size_t)i * 3 + k];
-    red[threadIdx.x] = s;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-      __syncthreads();
+__global__ __launch_bounds__(1024) void dec_finalize_kernel(const float* __restrict__ part, int nblk, int nout, float* __restrict__ out) {
+  __shared__ double red[3][1024];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < nblk; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < nout) s[k] += (double)part[(size_t)i * 3 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
     }
-    if (threadIdx.x == 0) out[k] = (float)red[0];
     __syncthreads();
   }
+  if ((int)threadIdx.x < nout) out[threadIdx.x] = (float)red[threadIdx.x][0];
 }
 
 // ------------------------------------------------------------------ edge-list form (any order)
@@ -395,7 +400,7 @@ extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, 
   }
 #undef CEEG_EDGE_CASE
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(256), 0, st, part, nblk, 1, loss_sum);
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, 1, loss_sum);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
@@ -450,7 +455,7 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   }
 #undef CEEG_DEC_CASE
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(256), 0, st, part, nslots, 3, sums);
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nslots, 3, sums);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

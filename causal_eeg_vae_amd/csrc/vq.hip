@@ -119,7 +119,7 @@ __device__ __forceinline__ float vq_block_sum(float v, float* red /* [VQ_WAVES] 
 // EXACT: D == DP (every 16-byte access is in bounds and aligned).  Otherwise the ragged tail is handled
 // with clamped scalar loads + selects (branch-free) and guarded scalar stores.
 template <int DP, bool EXACT>
-__global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
+__global__ __launch_bounds__(VQ_THREADS, (EXACT && DP <= 128) ? 3 : 2) void vq_main_f32(
     const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ ee,
     const float* __restrict__ img, int64_t B, int n_e, int D, int n_ep,
     float* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
@@ -142,12 +142,54 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
   const int r = lane & 15, q = lane >> 4;
   const int64_t row0 = (int64_t)blockIdx.x * BM + wave * ROWS_W;
 
-  // ---- z tile -> registers: lane (r,q) keeps z[r][4u+q] (the MFMA A operand of k-step u), loaded as
-  // dwords (16 rows x 16 B per wave-instruction; the kernel is MFMA-bound by >10x, L1 absorbs it).
-  // zz[r] is the natural-order fmaf chain over the whole row, computed redundantly by the row's 4 lanes.
+  // ---- z tile -> registers: lane (r,q) keeps z[r][4u+q] (the MFMA A operand of k-step u); zz[r] is the
+  // natural-order fmaf chain over the whole row, computed redundantly by the row's 4 lanes.
   // Rows past B are clamped to B-1 for the loads (their results are never stored).
+  constexpr bool VIA_LDS = EXACT && DP <= 128;  // wider rows: no LDS to spare at two blocks per CU
   float a[RT][NU];
   float zz[RT];
+  if constexpr (VIA_LDS) {
+    // A wave's 16-row tile is one contiguous 16*DP*4-byte block: fetch it with fully coalesced 16-byte loads
+    // (every 128-byte line touched once), park it in the wave's own LDS strip (row pitch DP+4 floats: the
+    // strided reads below hit 64 distinct banks), and pick the MFMA layout out of LDS.
+    constexpr int PITCH = DP + 4;
+    constexpr int PPR = DP / 4;            // 16-byte pieces per row
+    constexpr int NPC = 16 * PPR / 64;     // pieces per lane per tile
+    // the strips lie over chunk buffer 1 and the idx/red words (first written after the barrier that ends the prologue)
+    float* strip = reinterpret_cast<float*>(smem + CHB) + wave * 16 * PITCH;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      float4 pc[NPC];
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int p = j * 64 + lane;
+        int64_t row = row0 + rt * 16 + p / PPR;
+        row = row < B ? row : B - 1;
+        pc[j] = *reinterpret_cast<const float4*>(z + row * D + 4 * (p % PPR));
+      }
+#pragma unroll
+      for (int j = 0; j < NPC; ++j) {
+        const int p = j * 64 + lane;
+        *reinterpret_cast<float4*>(strip + (p / PPR) * PITCH + 4 * (p % PPR)) = pc[j];
+      }
+      asm volatile("" ::: "memory");
+      // same wave wrote and reads the strip: LDS operations of one wave complete in order
+      const float* zr = strip + r * PITCH;
+      float acc = 0.f;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(zr + 4 * u);
+        acc = __fmaf_rn(v.x, v.x, acc);
+        acc = __fmaf_rn(v.y, v.y, acc);
+        acc = __fmaf_rn(v.z, v.z, acc);
+        acc = __fmaf_rn(v.w, v.w, acc);
+        a[rt][u] = zr[4 * u + q];
+        if ((u & 7) == 7) asm volatile("" ::: "memory");  // register budget: <= 8 LDS reads in flight
+      }
+      zz[rt] = acc;
+      asm volatile("" ::: "memory");  // the next tile overwrites the strip only after these reads were issued
+    }
+  } else {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     int64_t row = row0 + rt * 16 + r;
@@ -183,6 +225,7 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
       if ((u & 7) == 7) asm volatile("" ::: "memory");  // keep <= 8 float4 loads in flight (register budget)
     }
     zz[rt] = acc;  // identical in the 4 q-lanes of row r
+  }
   }
   // zz of the rows this lane owns in the C layout (row = 4q + i)
   float zzc[RT][4];
@@ -257,6 +300,30 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
 
   // ---- z_q gather, squared error, idx
   float err = 0.f;
+  if constexpr (VIA_LDS) {
+    // the wave's ROWS_W output rows are one contiguous block: lane-consecutive 16-byte pieces, each the matching
+    // piece of its row's codebook row (L1/L2-resident) - stores and the z re-read are fully coalesced
+    constexpr int PPR = DP / 4;
+    constexpr int NP = ROWS_W * PPR / 64;
+    if (lane < ROWS_W && row0 + lane < B) idx_out[row0 + lane] = lds_idx[wave * ROWS_W + lane];
+#pragma unroll 4
+    for (int j = 0; j < NP; ++j) {
+      const int p = j * 64 + lane;
+      const int lr = p / PPR, c4 = 4 * (p % PPR);
+      const int64_t row = row0 + lr;
+      if (row < B) {
+        const int id = lds_idx[wave * ROWS_W + lr];
+        const float4 wv = *reinterpret_cast<const float4*>(W + (size_t)id * D + c4);
+        const float4 zv = *reinterpret_cast<const float4*>(z + row * D + c4);
+        *reinterpret_cast<float4*>(z_q + row * D + c4) = wv;
+        const float dx = wv.x - zv.x, dy = wv.y - zv.y, dz = wv.z - zv.z, dw = wv.w - zv.w;
+        err = __fmaf_rn(dx, dx, err);
+        err = __fmaf_rn(dy, dy, err);
+        err = __fmaf_rn(dz, dz, err);
+        err = __fmaf_rn(dw, dw, err);
+      }
+    }
+  } else {
 #pragma unroll
   for (int rt = 0; rt < RT; ++rt) {
     const int64_t row = row0 + rt * 16 + r;
@@ -291,6 +358,7 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_f32(
       }
     }
     err += live ? e : 0.f;
+  }
   }
   const float tot = vq_block_sum(err, lds_red);
   if (threadIdx.x == 0) err_part[blockIdx.x] = tot;
@@ -730,7 +798,11 @@ size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_b
 template <int DP>
 void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, float* z_q,
                 int64_t* idx, int64_t nblk, hipStream_t st) {
-  const size_t lds = 2 * (32 * DP * 4 + 32 * 4) + 128 * 4 + VQ_WAVES * 4;
+  size_t lds = 2 * (32 * DP * 4 + 32 * 4) + 128 * 4 + 16;
+  if (D == DP && DP <= 128) {  // per-wave z strips (VIA_LDS) overlay everything after chunk buffer 0
+    const size_t with_strips = (32 * DP * 4 + 32 * 4) + (size_t)VQ_WAVES * 16 * (DP + 4) * 4;
+    lds = lds > with_strips ? lds : with_strips;
+  }
   if (D == DP)
     hipLaunchKernelGGL((vq_main_f32<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
                        reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
