@@ -147,7 +147,7 @@ struct DecRowState {
   float s_pos, s_neg, s_cnt;
 };
 
-// One round = T gather steps (T*G entries of the current 64-entry batch, starting at step i0): gathers in flight together,
+// One round = T (<= 4: keeps the kernel near 112 VGPRs, 4 waves per SIMD) gather steps (T*G entries of the current 64-entry batch, starting at step i0): gathers in flight together,
 // 2T dot products reduced by the transposed butterfly, ONE evaluation of the sigmoid/log/derivative per 2T*G values
 // (spread over the lanes instead of repeated per step), then the coefficients go back to the lanes that still hold
 // the gathered pieces for the row-side gradient sums.
@@ -322,10 +322,9 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
         const int my_valid = (lane < n && my_c != cur.sr && !hit) ? 1 : 0;
         const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
         int i0 = 0;
-        for (; i0 + 8 <= ns; i0 += 8) dec_round<LPR, 8, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
         const int rem = ns - i0;  // one round of the next power of two covers the tail
-        if (rem > 4) dec_round<LPR, 8, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
-        else if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
         else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
         else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
       }
