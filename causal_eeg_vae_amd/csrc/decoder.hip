@@ -152,7 +152,7 @@ struct DecRowState {
 // (spread over the lanes instead of repeated per step), then the coefficients go back to the lanes that still hold
 // the gathered pieces for the row-side gradient sums.
 template <int LPR, int T, bool GRAD>
-__device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t ldz, int my_c, int my_valid, int base, int i0, int ns, int n,
+__device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t ldz, int my_g, int my_valid, int base, int i0, int ns, int n,
                                           int lane, bool fl_ok, float* __restrict__ coef_pos, float* __restrict__ coef_neg,
                                           DecRowState& st) {
   constexpr int G = 64 / LPR;
@@ -166,7 +166,7 @@ __device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t l
 #pragma unroll
   for (int k = 0; k < T; ++k) {
     const int j = (i0 + k) * G + sub;
-    const int c = __shfl(my_c, j & 63, 64);
+    const int c = __shfl(my_g, j & 63, 64);
     x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i0 + k < ns && j < n && fl_ok) x[k] = *reinterpret_cast<const float4*>(z + (int64_t)c * ldz + 4 * fl);
   }
@@ -233,6 +233,7 @@ constexpr size_t DEC_QUEUE_BYTES = 8 * 128;
 struct DecRow {     // everything a row needs before its gathers, fetched one row ahead
   int p_lo, p_hi, s_lo, s_hi, sr;
   int bc, sc;       // lane's entry of the row's first 64 columns / of row sigma(r)'s first 64 columns
+  int bg;           // row of z to gather for bc (bc itself, or zidx[bc] when z is a table)
   float4 zr, zs;
 };
 
@@ -250,8 +251,8 @@ struct DecRow {     // everything a row needs before its gathers, fetched one ro
 // against sigma(r)'s columns held across the lanes (memory binary search only for sigma-rows longer than 64).
 template <int LPR, bool GRAD>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
-    const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int D,
-    int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
+    const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, int64_t N, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
     float* __restrict__ grow_neg, int64_t ldg, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed */,
     float* __restrict__ part) {
   constexpr int G = 64 / LPR;
@@ -274,12 +275,15 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     if (lane == 0) dv = atomicAdd(q, (unsigned)DEC_ROWS);  // the next draw lands while these rows run
     const int cnt = r_end - base_r < DEC_ROWS ? (int)(r_end - base_r) : DEC_ROWS;
     st.s_pos = st.s_neg = st.s_cnt = 0.f;
-    int rp = 0, sri = 0, sp_lo = 0, sp_hi = 0;
+    int rp = 0, sri = 0, sp_lo = 0, sp_hi = 0, gri = 0, gsi = 0;
     if (lane <= cnt) rp = rowptr[base_r + lane];
     if (lane < cnt) {
       sri = (int)ceeg_block_affine(base_r + lane, sig_a, sig_b, sig_mod);
       sp_lo = rowptr[sri];
       sp_hi = rowptr[sri + 1];
+      gri = (int)(base_r + lane);
+      gsi = sri;
+      if (zidx) { gri = zidx[gri]; gsi = zidx[gsi]; }
     }
     auto fetch = [&](int i) -> DecRow {
       DecRow w;
@@ -288,13 +292,16 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
       w.s_lo = __builtin_amdgcn_readlane(sp_lo, i);
       w.s_hi = __builtin_amdgcn_readlane(sp_hi, i);
       w.sr = __builtin_amdgcn_readlane(sri, i);
-      w.bc = 0; w.sc = 0; w.zr = zero4; w.zs = zero4;
+      w.bc = 0; w.sc = 0; w.bg = 0; w.zr = zero4; w.zs = zero4;
       if (w.p_lo != w.p_hi) {
-        if (lane < w.p_hi - w.p_lo) w.bc = col[w.p_lo + lane];
+        if (lane < w.p_hi - w.p_lo) {
+          w.bc = col[w.p_lo + lane];
+          w.bg = zidx ? zidx[w.bc] : w.bc;
+        }
         if (lane < w.s_hi - w.s_lo) w.sc = col[w.s_lo + lane];
         if (fl_ok) {
-          w.zr = *reinterpret_cast<const float4*>(z + (base_r + i) * ldz + 4 * fl);
-          w.zs = *reinterpret_cast<const float4*>(z + (int64_t)w.sr * ldz + 4 * fl);
+          w.zr = *reinterpret_cast<const float4*>(z + (int64_t)__builtin_amdgcn_readlane(gri, i) * ldz + 4 * fl);
+          w.zs = *reinterpret_cast<const float4*>(z + (int64_t)__builtin_amdgcn_readlane(gsi, i) * ldz + 4 * fl);
         }
       }
       return w;
@@ -311,8 +318,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
       const int s_n = cur.s_hi - cur.s_lo;
       for (int base = cur.p_lo; base < cur.p_hi; base += 64) {
         const int n = cur.p_hi - base < 64 ? cur.p_hi - base : 64;
-        int my_c = cur.bc;
-        if (base != cur.p_lo) my_c = lane < n ? col[base + lane] : 0;
+        int my_c = cur.bc, my_g = cur.bg;
+        if (base != cur.p_lo) {
+          my_c = lane < n ? col[base + lane] : 0;
+          my_g = (zidx && lane < n) ? zidx[my_c] : my_c;
+        }
         bool hit = false;
         if (s_n <= 64) {
           for (int t = 0; t < s_n; ++t) hit |= (my_c == __builtin_amdgcn_readlane(cur.sc, t));
@@ -322,11 +332,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
         const int my_valid = (lane < n && my_c != cur.sr && !hit) ? 1 : 0;
         const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
         int i0 = 0;
-        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
         const int rem = ns - i0;  // one round of the next power of two covers the tail
-        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
-        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
-        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_c, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
       }
       if constexpr (GRAD) {
         if constexpr (G > 1) {
@@ -412,7 +422,7 @@ extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
   return (a > b ? a : b) > a0 ? (a > b ? a : b) : a0;
 }
 
-extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                                       float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
                                       float* sums, void* ws, size_t ws_bytes, void* stream) {
@@ -436,10 +446,10 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
 #define CEEG_DEC_CASE(L)                                                                                                              \
   case L:                                                                                                                             \
     if (grow_pos)                                                                                                                     \
-      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
+      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
                          sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     else                                                                                                                              \
-      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, rowptr, col, N, D, sig_a, \
+      hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
                          sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
     break;
   switch (lpr) {
@@ -459,7 +469,7 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   return CEEG_OK;
 }
 
-extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                                       const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
                                       const float* coef_pos, const float* coef_neg, const float* grow_pos,
@@ -478,14 +488,14 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
     // the forward already holds the row-side sums (terms (1) and (3) below); two transposed passes finish the job:
     //   dz[n]  = gp * (grow_pos[n] + sum_{q in trow n} cp[tperm q] z[tcol q])
     //   dz[n] += gn * (grow_neg[n] + sum_{q in trow n} cn[tperm q] z[sigma(tcol q)])
-    CeegSpmmEx t2; t2.mod = sig_mod; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg;
+    CeegSpmmEx t2; t2.mod = sig_mod; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg; t2.xidx = zidx;
     rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, t2);
     if (rc != CEEG_OK) return rc;
     CeegSpmmEx t4 = t2; t4.scale = gscale + 1; t4.col_a = sig_a; t4.col_b = sig_b; t4.addend = grow_neg;
     return ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, t4);
   }
   // (1) n as dst of positives:            dz[n]  = gp * sum_{p in row n} cp[p] z[col p]
-  CeegSpmmEx e1; e1.mod = sig_mod; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz;
+  CeegSpmmEx e1; e1.mod = sig_mod; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz; e1.xidx = zidx;
   CeegSpmmEx e2 = e1; e2.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_pos, nullptr, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, e1);
   if (rc != CEEG_OK) return rc;
@@ -493,11 +503,11 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e2);
   if (rc != CEEG_OK) return rc;
   // (3) n = sigma(r) as negative endpoint: dz[sigma(r)] += gn * sum_{p in row r} cn[p] z[col p]
-  CeegSpmmEx e3; e3.mod = sig_mod; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz;
+  CeegSpmmEx e3; e3.mod = sig_mod; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz; e3.xidx = zidx;
   rc = ceeg_spmm_launch(rowptr, col, coef_neg, nullptr, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e3);
   if (rc != CEEG_OK) return rc;
   // (4) n as src of negatives:            dz[n] += gn * sum_{q in trow n} cn[tperm q] z[sigma(tcol q)]
-  CeegSpmmEx e4; e4.mod = sig_mod; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz;
+  CeegSpmmEx e4; e4.mod = sig_mod; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz; e4.xidx = zidx;
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e4);
   return rc;
 }

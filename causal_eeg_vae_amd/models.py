@@ -85,6 +85,9 @@ class EventGraph:
         _lib.check(L.ceeg_gcn_norm(self.gcn.rowptr.data_ptr(), self.gcn.col.data_ptr(), self.gcn.perm.data_ptr(), _lib.ptr(ew),
                                    self.gcn.nnz, self.num_nodes, self.dinv.data_ptr(), self.gcn_val.data_ptr(), _lib.stream()),
                    "ceeg_gcn_norm")
+        # values in the transposed order, gathered once: the backward SpMM then streams them instead of chasing
+        # val[t_perm[q]] (a dependent load in front of every row's gathers)
+        self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
         self._dec = None
 
     @property
@@ -161,7 +164,7 @@ class _GcnAggregate(torch.autograd.Function):
             grad, dbias = _relu_bwd_colsum(grad, out)
         else:
             dbias = _colsum(grad) if ctx.has_bias else None
-        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_val, g.t_perm, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
+        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
 
@@ -403,12 +406,21 @@ class _FusedDecoder(torch.autograd.Function):
     """recon_loss with permutation-structured negatives: one gather pass for both terms (ceeg_decoder_fused_*)."""
 
     @staticmethod
-    def forward(ctx, z, graph, a, b, ainv, row_sums=True, sig_mod=None):
+    def forward(ctx, z, graph, a, b, ainv, row_sums=True, sig_mod=None, table=None, table_idx=None):
+        """table / table_idx: a quantised latent given as (codebook [n_e, D], int32 code per node) with
+        z[n] == table[table_idx[n]] bit for bit (what VectorQuantizer's forward returns in fp32): the kernels then
+        gather codebook rows through the 4-byte index instead of D*4-byte rows of z.  Gradients still flow to z."""
         _lib.require_cuda(z)
         L = _lib.lib()
-        z = z.contiguous()
         N, D = z.shape
         mod = int(N if sig_mod is None else sig_mod)
+        if table is not None:
+            src, sidx = table.detach().contiguous(), table_idx.contiguous()
+            if src.shape[1] != D or sidx.shape[0] != N or sidx.dtype != torch.int32:
+                raise ValueError("table must be [n_e, D] and table_idx int32 [N]")
+        else:
+            src, sidx = z.contiguous(), None
+        z = src
         p = graph.dec
         cp = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
         cn = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
@@ -417,12 +429,13 @@ class _FusedDecoder(torch.autograd.Function):
         grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         with _lib.timed("decoder_fwd"):
-            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
+            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
                                                 cp.data_ptr(), cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
         ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
         ctx.save_for_backward(z, cp, cn, inv)
+        ctx.sidx, ctx.shape = sidx, (N, D)
         ctx.graph, ctx.sig = graph, (a, b, ainv, mod)
         ctx.mark_non_differentiable(sums)
         return sums[0] * inv[0] + sums[1] * inv[1], sums
@@ -431,21 +444,22 @@ class _FusedDecoder(torch.autograd.Function):
     def backward(ctx, g, _gs):
         z, cp, cn, inv = ctx.saved_tensors
         L = _lib.lib()
-        N, D = z.shape
+        N, D = ctx.shape
         p = ctx.graph.dec
+        sidx = ctx.sidx
         a, b, ainv, mod = ctx.sig
         gscale = (inv * g).contiguous()
-        dz = torch.empty_like(z)
+        dz = torch.empty(N, D, dtype=torch.float32, device=z.device)
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         grow = ctx.grow
         with _lib.timed("decoder_bwd"):
-            _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
+            _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
                                                 p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, mod, cp.data_ptr(),
                                                 cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
                                                 _lib.stream()), "ceeg_decoder_fused_bwd")
         ctx.grow = None
-        return dz, None, None, None, None, None, None
+        return dz, None, None, None, None, None, None, None, None
 
 
 # ==================================================================================================
@@ -540,7 +554,9 @@ class VGAEVQ(nn.Module):
         z, kl = _ReparamKL.apply(ml, None, eps, seed, self.training, False)
         vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
         a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
-        rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv)
+        # z_q is bit-for-bit codebook[idx] in fp32: let the decoder gather 512 codebook rows through idx
+        rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, None, self.vector_quantization.embedding.weight,
+                                        idx.view(-1).to(torch.int32))
         loss = rec + kl / N + vq_loss
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
 

@@ -167,12 +167,15 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
  * sums[0]=sum pos terms, sums[1]=sum valid neg terms, sums[2]=number of valid negatives (as float),
  * all written to `sums` (3 floats, device).  rowptr/col: CSR WITHOUT self-loops (ceeg_csr_build
  * self_loops=0).
+ * zidx (int32 [N] or NULL): when the latent is QUANTISED, node n's row is z[zidx[n]] and `z` is the codebook
+ * ([n_e, ldz], a few hundred KB that stay in L1/L2) - the gathers then cost 4 bytes of HBM per edge instead of a
+ * D*4-byte row.  Entries must lie in [0, n_e); the result is identical to passing the expanded [N, D] matrix.
  * grow_pos / grow_neg ([N, ldg] fp32, both or neither; NULL when no gradient is wanted): the row-side halves of
  * dz, accumulated while the gathered pieces are still in registers (unscaled):
  *   grow_pos[r] = sum_{p in row r} cp[p] z[col p],   grow_neg[sigma(r)] = sum_{p in row r} cn[p] z[col p].
  * Handing them to ceeg_decoder_fused_bwd leaves it two gather passes instead of four. */
 size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
-int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                            float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
                            float* sums, void* ws, size_t ws_bytes, void* stream);
@@ -184,7 +187,7 @@ int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* rowptr, c
  *         + sum_{q in trow n} gn*cn[tperm q] z[sigma(tcol q)]  (n as src of negatives)
  * sig_ainv = a^-1 mod N.  With grow_pos/grow_neg from the forward (both non-NULL) the first and third sums are
  * taken from those tables and only the two transposed passes run; with NULL all four passes run. */
-int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* rowptr, const int32_t* col,
+int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                            const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
                            const float* coef_pos, const float* coef_neg, const float* grow_pos,

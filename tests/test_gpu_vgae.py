@@ -216,3 +216,26 @@ def test_conditional_batched_step_vs_oracle(per_graph):
         ref_params = dict(ref.named_parameters())
         for name, p in model.named_parameters():
             _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
+
+
+@pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (1000, 30000, 32, 16)])
+def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e):
+    """Quantised latent passed as (codebook, int32 code per node): same loss, counts and gradient - bit for bit - as
+    the expanded [N, D] matrix (include/ceeg.h, zidx of ceeg_decoder_fused_fwd / _bwd)."""
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    g = EventGraph(torch.from_numpy(_graph(N, E, 5)).cuda(), N)
+    a_, b_, ainv = sigma_params(N, 1, 9)
+    torch.manual_seed(3)
+    W = (torch.randn(n_e, D) * (2.0 / D ** 0.5)).cuda()
+    idx = torch.randint(0, n_e, (N,), dtype=torch.int32).cuda()
+    zq = W[idx.long()]
+    for row_sums in (True, False):
+        x1 = zq.clone().requires_grad_(True)
+        r1, s1 = _FusedDecoder.apply(x1, g, a_, b_, ainv, row_sums)
+        (r1 * 0.7).backward()
+        x2 = zq.clone().requires_grad_(True)
+        r2, s2 = _FusedDecoder.apply(x2, g, a_, b_, ainv, row_sums, None, W, idx)
+        (r2 * 0.7).backward()
+        assert torch.equal(r1, r2) and torch.equal(s1, s2)
+        assert torch.equal(x1.grad, x2.grad)
