@@ -310,6 +310,7 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
   int64_t per_xcd = (N + 8 * SPMM_GRAB - 1) / (8 * SPMM_GRAB);  // blocks per XCD: enough for one draw each ...
   static const int bpx_cap = getenv("CEEG_SPMM_BPX") ? atoi(getenv("CEEG_SPMM_BPX")) : SPMM_BLOCKS_PER_XCD;  // tuning knob
   if (per_xcd > bpx_cap) per_xcd = bpx_cap;  // ... capped at 8 resident blocks on each of 32 CUs
+  if (per_xcd < SPMM_SUBQ) per_xcd = SPMM_SUBQ;  // every interleaved sub-queue needs a workgroup that drains it (tiny graphs)
   hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)(8 * per_xcd)), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx,
                      N, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, ex);
   CEEG_CHECK_LAUNCH();

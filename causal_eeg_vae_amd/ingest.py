@@ -1,0 +1,90 @@
+"""Event-graph ingestion: the on-disk CSV pair of the reference -> `edge_index` (+ `entities` weights), and the
+ancestor-subgraph extraction its dataset builder runs per target node.
+
+Follows /root/reference/scripts/dataset.py:
+  * :122-153  nodes `dropna()` + `drop_duplicates(subset='title')`; edges whose endpoints were dropped are skipped;
+              parallel (old_id, new_id) rows collapse into one directed edge whose `entities` counts them;
+  * :22-33    `get_top_n_valid_predecessors`: predecessors with entities >= MIN_COMMON_ENTITIES, heaviest first
+              (stable: ties keep the order in which the edges first appeared), at most n;
+  * :35-46    `get_n_gen_ancestors`: the union of those predecessors over NUM_GENERATIONS generations.
+Host-side preprocessing (runs once per dataset, numpy/pandas on the CPU like the reference's); the tensors it
+returns feed `EventGraph(edge_index, num_nodes, edge_weight=entities)`.  Nodes are numbered 0..n-1 in the order
+of the cleaned node table (the reference labels them with the table's index; `node_ids[i]` is the CSV `id`).
+"""
+import numpy as np
+
+MAX_TOP_PREDECESSORS = 3   # dataset.py:16
+NUM_GENERATIONS = 3        # dataset.py:17
+MIN_COMMON_ENTITIES = 3    # dataset.py:18
+
+
+def load_event_graph_csv(nodes_csv, edges_csv):
+    """-> dict(edge_index [2,E] int64 (row 0 = old_id = source, row 1 = new_id = target), entities [E] int64,
+    num_nodes, node_ids [n] (CSV ids), titles [n])."""
+    import pandas as pd
+    nodes = pd.read_csv(nodes_csv).dropna().drop_duplicates(subset="title")   # dataset.py:126-133
+    edges = pd.read_csv(edges_csv)
+    ids = nodes["id"].to_numpy()
+    pos = {int(v): i for i, v in enumerate(ids)}
+    first = {}
+    src, dst, cnt = [], [], []
+    for o, n in zip(edges["old_id"].to_numpy(), edges["new_id"].to_numpy()):  # dataset.py:145-156
+        if int(o) not in pos or int(n) not in pos:
+            continue
+        key = (pos[int(o)], pos[int(n)])
+        if key in first:
+            cnt[first[key]] += 1
+        else:
+            first[key] = len(src)
+            src.append(key[0]); dst.append(key[1]); cnt.append(1)
+    ei = np.array([src, dst], dtype=np.int64).reshape(2, -1)
+    return dict(edge_index=ei, entities=np.array(cnt, dtype=np.int64), num_nodes=len(ids), node_ids=ids.astype(np.int64),
+                titles=nodes["title"].tolist())
+
+
+class PredecessorIndex:
+    """In-edges grouped by target, in first-appearance order (what networkx's `predecessors` iterates)."""
+
+    def __init__(self, edge_index, entities, num_nodes):
+        ei = np.asarray(edge_index)
+        order = np.argsort(ei[1], kind="stable")
+        self.src = ei[0][order]
+        self.w = np.asarray(entities)[order]
+        self.ptr = np.zeros(num_nodes + 1, dtype=np.int64)
+        np.add.at(self.ptr, ei[1] + 1, 1)
+        self.ptr = np.cumsum(self.ptr)
+
+    def top_predecessors(self, node, n, min_entities=MIN_COMMON_ENTITIES):
+        lo, hi = self.ptr[node], self.ptr[node + 1]
+        s, w = self.src[lo:hi], self.w[lo:hi]
+        keep = w >= min_entities
+        s, w = s[keep], w[keep]
+        order = np.argsort(-w, kind="stable")          # sorted(..., reverse=True) is stable
+        return s[order][: min(n, hi - lo)].tolist()
+
+    def ancestors(self, node, num_gens=NUM_GENERATIONS, num_predecessors=MAX_TOP_PREDECESSORS):
+        """dataset.py:35-46 without the recursion: generation-by-generation frontier expansion."""
+        if num_gens == 0:
+            return {int(node)}
+        out, frontier = set(), [int(node)]
+        for g in range(num_gens):
+            nxt = []
+            for v in frontier:
+                for p in self.top_predecessors(v, num_predecessors):
+                    out.add(int(p))
+                    nxt.append(int(p))
+            if g == num_gens - 1:   # the reference's base case adds the last generation's nodes themselves
+                out.update(nxt)
+            frontier = nxt
+        return out
+
+
+def ancestor_subgraph(edge_index, entities, num_nodes, node, index=None):
+    """Induced subgraph on the ancestors of `node` (dataset.py:201-225): (local edge_index [2,e], node list)."""
+    idx = PredecessorIndex(edge_index, entities, num_nodes) if index is None else index
+    keep = sorted(idx.ancestors(node))
+    loc = {v: i for i, v in enumerate(keep)}
+    ei = np.asarray(edge_index)
+    m = np.isin(ei[0], keep) & np.isin(ei[1], keep)
+    sub = np.array([[loc[int(a)] for a in ei[0][m]], [loc[int(b)] for b in ei[1][m]]], dtype=np.int64).reshape(2, -1)
+    return sub, keep

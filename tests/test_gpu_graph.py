@@ -85,6 +85,29 @@ def test_spmm_vs_oracle_and_determinism(F):
     torch.testing.assert_close(lhs, rhs, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("N,E", [(1, 0), (2, 1), (7, 12), (33, 100), (96, 145), (130, 900)])
+def test_spmm_tiny_graphs(N, E):
+    """Graphs smaller than one queue draw per workgroup / XCD (every row must still be drained), empty edge lists."""
+    from causal_eeg_vae_amd import EventGraph
+    from causal_eeg_vae_amd.models import _spmm
+    from oracle import ref_torch
+    rng = np.random.default_rng(N)
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    g = EventGraph(torch.from_numpy(np.stack([src, dst])).cuda(), N)
+    rowptr, col, perm = ref_torch.csr_build_np(src, dst, N, True)
+    _, val = ref_torch.gcn_norm_np(rowptr, col, perm, None, N)
+    t_rowptr, t_col, t_perm = ref_torch.csr_transpose_np(rowptr, col, N)
+    for F in (4, 16, 128):
+        x = torch.randn(N, F, device="cuda")
+        out = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, x, N)
+        ref = ref_torch.spmm_np(rowptr, col, val, x.cpu().numpy())
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=1e-6 * max(np.abs(ref).max(), 1e-30))
+        outT = _spmm(g.gcn.t_rowptr, g.gcn.t_col, g.gcn_tval, None, x, N)
+        refT = ref_torch.spmm_np(t_rowptr, t_col, val[t_perm], x.cpu().numpy())
+        np.testing.assert_allclose(outT.cpu().numpy(), refT, rtol=1e-5, atol=1e-6 * max(np.abs(refT).max(), 1e-30))
+
+
 def test_negative_sampling_bit_exact():
     from causal_eeg_vae_amd import negative_sampling, CsrPair
     from oracle import c_oracle, ref_torch

@@ -239,3 +239,42 @@ def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e):
         (r2 * 0.7).backward()
         assert torch.equal(r1, r2) and torch.equal(s1, s2)
         assert torch.equal(x1.grad, x2.grad)
+
+
+def test_config1_plumbing_csv_to_training(tmp_path):
+    """BASELINE config 1 as plumbing: an event-graph CSV pair of the reference's schema and size (97 node rows, 234
+    edge rows; synthetic content) -> ingestion -> `entities`-weighted GCNConv vs the oracle -> a few VGAE+VQ
+    optimizer steps on the tiny graph (N not a multiple of anything, isolated nodes, DAG)."""
+    pd = pytest.importorskip("pandas")
+    from causal_eeg_vae_amd import EventGraph, GCNConv, VGAEVQ, ingest
+    from causal_eeg_vae_amd.trainer import Trainer
+    from oracle import ref_torch
+    rng = np.random.default_rng(0)
+    n, rows = 97, 234
+    ids = rng.permutation(200)[:n]
+    nodes = pd.DataFrame({"title": [f"t{i}" for i in range(n)], "text": "x", "publish_date": "d", "url": "u", "id": ids})
+    nodes.loc[3, "text"] = np.nan
+    dst = rng.integers(1, n, rows)
+    src = (dst * rng.random(rows) ** 2).astype(np.int64)
+    rep = rng.integers(0, 40, rows)
+    src, dst = np.where(rep < 8, src[rep], src), np.where(rep < 8, dst[rep], dst)
+    edges = pd.DataFrame({"old_id": ids[src], "new_id": ids[dst], "entity": "e", "entity_type": "LOC", "date_diff": 1})
+    nodes.to_csv(tmp_path / "p_nodes.csv", index=False)
+    edges.to_csv(tmp_path / "p_edges.csv", index=False)
+    g = ingest.load_event_graph_csv(str(tmp_path / "p_nodes.csv"), str(tmp_path / "p_edges.csv"))
+    N = g["num_nodes"]
+    assert N == 96 and g["entities"].max() >= 3
+    keep = g["edge_index"][0] != g["edge_index"][1]
+    ei = torch.from_numpy(g["edge_index"][:, keep])
+    ew = torch.from_numpy(g["entities"][keep]).float()
+    graph = EventGraph(ei.cuda(), N, ew.cuda())
+    torch.manual_seed(0)
+    x = torch.randn(N, 32)
+    ref = ref_torch.RefGCNConv(32, 16)
+    conv = GCNConv(32, 16).cuda()
+    conv.load_state_dict(ref.state_dict())
+    _close(conv(x.cuda(), graph), ref(x, ei, ew))
+    model = VGAEVQ(32, 8, 16, 0.25).cuda()
+    tr = Trainer(model, lr=1e-2)
+    losses = [float(tr.step(x.cuda(), graph)[0]) for _ in range(30)]
+    assert all(np.isfinite(losses)) and np.mean(losses[-5:]) < np.mean(losses[:5])
