@@ -203,6 +203,15 @@ def main():
         spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * F * 4
         launches, spmm_ms = prof.get(f"spmm_F{F}", (0, float("nan")))  # layer-2 aggregation (fwd) and its transposed pass (bwd)
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
+        # HBM-side bytes per launch from the rocprofv3 PMC passes of this round (profiles/r01_step_pmc_hbm.txt);
+        # counters cannot be read from inside the process, so the figure is reported only for the workload it was
+        # measured on
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_spmm_traffic.json")
+        if os.path.exists(tpath):
+            t = json.load(open(tpath))
+            if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F):
+                traffic = t["traffic_bytes"]
         line = {"metric": "VGAE train edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -211,7 +220,7 @@ def main():
                            "parallelism": f"dp{world}"},
                 "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr F={F} (spmm_rows_kernel<64> + long-row pieces)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": None, "launches_timed": launches, "avg_launch_ms": spmm_ms,
+                             "traffic": traffic, "launches_timed": launches, "avg_launch_ms": spmm_ms,
                              "algorithmic_bytes_per_launch": spmm_bytes},
                 "loss": float(loss.item())}
         if world == 1 and not args.no_cpu_baseline:
