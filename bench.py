@@ -85,11 +85,25 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
+    # one rank per GPU; CEEG_DIST_BACKEND=gloo + CEEG_SHARE_GPU=1 is the one-GPU rehearsal of the multi-process path
+    backend = os.environ.get("CEEG_DIST_BACKEND", "nccl")
+    if os.environ.get("CEEG_SHARE_GPU") == "1":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
+    verbose = os.environ.get("CEEG_BENCH_VERBOSE") == "1"
+
+    def note(msg):
+        if verbose:
+            print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    note("process group up")
     from causal_eeg_vae_amd import _lib, EventGraph, VGAEVQ, VectorQuantizer
     from causal_eeg_vae_amd.synth import synth_event_graph, synth_features
     from causal_eeg_vae_amd.trainer import Trainer
@@ -153,6 +167,8 @@ def main():
         barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
         if world > 1:
+            if backend != "nccl":
+                t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         if rank == 0:
@@ -175,11 +191,14 @@ def main():
     model = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank).to(dev)
     with torch.no_grad():
         model.vector_quantization.embedding.weight.normal_(0, 0.1)
+    note("graph built")
     trainer = Trainer(model, lr=1e-3, world_size=world)
+    note("parameters broadcast")
 
     for _ in range(args.warmup):
         trainer.step(x, graph)
     barrier()
+    note("warm-up done")
     _lib.PROFILE = {}
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -193,6 +212,8 @@ def main():
         sys.exit(3)
     t = torch.tensor([el], dtype=torch.float64, device=dev)
     if world > 1:
+        if backend != "nccl":
+            t = t.cpu()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
     if rank == 0:

@@ -11,7 +11,13 @@ def allreduce_grads_(params, world_size):
     if not grads or world_size <= 1:
         return
     flat = torch._utils._flatten_dense_tensors(grads)
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal only (ranks sharing one GPU over gloo): gloo's device path dead-locks there, stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # RCCL: in place on the device, stream-ordered
     flat.div_(world_size)
     for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
         g.copy_(f)
