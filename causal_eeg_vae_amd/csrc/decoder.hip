@@ -5,6 +5,7 @@
 // cross-lane butterfly, the per-edge derivative d(term)/dv is stored so the backward is a pair of
 // deterministic SpMMs (spmm.hip) — no float atomics anywhere.  Loss sums: thread -> wave butterfly ->
 // block -> one fp64 pass over the block partials (fixed order).
+#include <stdlib.h>
 #include "ceeg_internal.h"
 
 namespace {
@@ -153,7 +154,7 @@ struct DecRowState {
 // the gathered pieces for the row-side gradient sums.
 template <int LPR, int T, bool GRAD>
 __device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t ldz, int my_g, int my_valid, int base, int i0, int ns, int n,
-                                          int lane, bool fl_ok, float* __restrict__ coef_pos, float* __restrict__ coef_neg,
+                                          int lane, bool fl_ok, float* __restrict__ coef_pos, float* __restrict__ coef_neg, int cstride,
                                           DecRowState& st) {
   constexpr int G = 64 / LPR;
   constexpr int M = dec_log2(LPR);
@@ -195,7 +196,7 @@ __device__ __forceinline__ void dec_round(const float* __restrict__ z, int64_t l
     const bool live = ok && (kind == 0 || vld != 0);
     if (!live) { term = 0.f; coef = 0.f; }
     if (ok && writer) {
-      (kind ? coef_neg : coef_pos)[base + j] = coef;
+      (kind ? coef_neg : coef_pos)[(int64_t)(base + j) * cstride] = coef;
       if (kind == 0) st.s_pos += term;
       else if (vld) { st.s_neg += term; st.s_cnt += 1.0f; }
     }
@@ -252,7 +253,7 @@ struct DecRow {     // everything a row needs before its gathers, fetched one ro
 template <int LPR, bool GRAD>
 __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ col, int64_t N, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, float* __restrict__ grow_pos,
+    const int32_t* __restrict__ col, int64_t N, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, int cstride, float* __restrict__ grow_pos,
     float* __restrict__ grow_neg, int64_t ldg, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed */,
     float* __restrict__ part) {
   constexpr int G = 64 / LPR;
@@ -332,11 +333,11 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
         const int my_valid = (lane < n && my_c != cur.sr && !hit) ? 1 : 0;
         const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
         int i0 = 0;
-        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
         const int rem = ns - i0;  // one round of the next power of two covers the tail
-        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
-        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
-        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, st);
+        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
       }
       if constexpr (GRAD) {
         if constexpr (G > 1) {
@@ -361,6 +362,229 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     if (lane == 0) {
       float* o = part + (size_t)(base_r / DEC_ROWS + xcd) * 3;
       o[0] = t0; o[1] = t1; o[2] = t2;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ fused backward: both transposed passes in one
+// Row n of the transposed CSR lists the entries q whose SOURCE is n (tcol q = the destination r, tperm q = the entry's
+// position p in the dst-sorted CSR).  One kernel accumulates both column-side halves of the gradient
+//     s1 = sum_q cp[p] z[r]          s2 = sum_q cn[p] z[sigma(r)]
+// and finishes   dz[n] = gn*(grow_neg[n] + s2) + gp*(grow_pos[n] + s1).
+// The (tcol, tperm) streams and the coefficient pair (interleaved: one sector per entry) are read once instead of
+// once per pass and dz is written once.  Summation order and rounding are exactly those of the two-pass form over
+// spmm.hip (lane group g adds entries g, g+G, ... ascending, fixed butterfly, long rows cut at global positions
+// k*DEC_CHUNK with partials added in ascending order), so both forms give bitwise equal results.
+constexpr int DEC_CHUNK = 256;
+
+struct DecBwdArgs {
+  const int32_t *t_rowptr, *t_col, *t_perm, *zidx;
+  const float *coef_pos, *coef_neg, *z, *grow_pos, *grow_neg, *gscale;
+  float* dz;
+  float* partial;        // [chunk][slot 0/1][sum 1/2][4*LPR]
+  unsigned int* queue;
+  int64_t ldz, ldg, lddz, N, sig_a, sig_b, sig_mod;
+  int cstride, D;
+};
+
+struct DecBwdBatch {   // lane's entry of a 64-entry batch, ready to gather
+  int g1, g2;
+  float c1, c2;
+};
+
+__device__ __forceinline__ void dec_bwd_raw(const DecBwdArgs& a, int base, int p_hi, int lane, int& rc, int& rp) {
+  rc = 0;
+  rp = 0;
+  if (base + lane < p_hi) {
+    rc = a.t_col[base + lane];
+    rp = a.t_perm[base + lane];
+  }
+}
+__device__ __forceinline__ DecBwdBatch dec_bwd_resolve(const DecBwdArgs& a, int base, int p_hi, int lane, int rc, int rp) {
+  DecBwdBatch b;
+  b.g1 = 0; b.g2 = 0; b.c1 = 0.f; b.c2 = 0.f;
+  if (base + lane < p_hi) {
+    const int s = (int)ceeg_block_affine((int64_t)rc, a.sig_a, a.sig_b, a.sig_mod);
+    b.g1 = a.zidx ? a.zidx[rc] : rc;
+    b.g2 = a.zidx ? a.zidx[s] : s;
+    b.c1 = a.coef_pos[(int64_t)rp * a.cstride];
+    b.c2 = a.coef_neg[(int64_t)rp * a.cstride];
+  }
+  return b;
+}
+
+template <int LPR, int K>
+__device__ __forceinline__ void dec_bwd_steps(const DecBwdArgs& a, const DecBwdBatch& b, int i0, int n, int lane, bool fl_ok,
+                                              float4& s1, float4& s2) {
+  constexpr int G = 64 / LPR;
+  const int fl = lane % LPR, sub = lane / LPR;
+  float4 x1[K], x2[K];
+  float v1[K], v2[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int j = (i0 + k) * G + sub;
+    const int g1 = __shfl(b.g1, j & 63, 64), g2 = __shfl(b.g2, j & 63, 64);
+    v1[k] = __shfl(b.c1, j & 63, 64);
+    v2[k] = __shfl(b.c2, j & 63, 64);
+    x1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    x2[k] = x1[k];
+    if (j < n && fl_ok) {
+      x1[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)g1 * a.ldz + 4 * fl);
+      x2[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)g2 * a.ldz + 4 * fl);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    if ((i0 + k) * G + sub >= n) continue;  // lanes past the batch end add nothing
+    s1.x = __fmaf_rn(v1[k], x1[k].x, s1.x); s1.y = __fmaf_rn(v1[k], x1[k].y, s1.y);
+    s1.z = __fmaf_rn(v1[k], x1[k].z, s1.z); s1.w = __fmaf_rn(v1[k], x1[k].w, s1.w);
+    s2.x = __fmaf_rn(v2[k], x2[k].x, s2.x); s2.y = __fmaf_rn(v2[k], x2[k].y, s2.y);
+    s2.z = __fmaf_rn(v2[k], x2[k].z, s2.z); s2.w = __fmaf_rn(v2[k], x2[k].w, s2.w);
+  }
+}
+
+// both sums over positions [p_lo, p_hi); `first` holds the resolved first batch
+template <int LPR>
+__device__ __forceinline__ void dec_bwd_seg(const DecBwdArgs& a, int p_lo, int p_hi, int lane, bool fl_ok, DecBwdBatch b,
+                                            float4& s1, float4& s2) {
+  constexpr int G = 64 / LPR;
+  s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+  s2 = s1;
+  for (int base = p_lo; base < p_hi; base += 64) {
+    const int n = p_hi - base < 64 ? p_hi - base : 64;
+    if (base != p_lo) {
+      int rc, rp;
+      dec_bwd_raw(a, base, p_hi, lane, rc, rp);
+      b = dec_bwd_resolve(a, base, p_hi, lane, rc, rp);
+    }
+    const int ns = (n + G - 1) / G;
+    int i0 = 0;
+    for (; i0 + 4 <= ns; i0 += 4) dec_bwd_steps<LPR, 4>(a, b, i0, n, lane, fl_ok, s1, s2);
+    const int rem = ns - i0;
+    if (rem & 2) { dec_bwd_steps<LPR, 2>(a, b, i0, n, lane, fl_ok, s1, s2); i0 += 2; }
+    if (rem & 1) dec_bwd_steps<LPR, 1>(a, b, i0, n, lane, fl_ok, s1, s2);
+  }
+  if constexpr (G > 1) {
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) {
+      s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+      s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
+    }
+  }
+}
+
+__device__ __forceinline__ int dec_row_of(const int32_t* __restrict__ rowptr, int64_t N, int p) {
+  int64_t lo = 0, hi = N;  // last r in [0,N) with rowptr[r] <= p
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= p) lo = mid; else hi = mid;
+  }
+  return (int)lo;
+}
+
+// pieces of long rows: wave w handles global positions [w*DEC_CHUNK, (w+1)*DEC_CHUNK)
+template <int LPR>
+__global__ __launch_bounds__(DEC_WAVES * 64) void dec_bwd_long_kernel(DecBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * DEC_WAVES + (threadIdx.x >> 6);
+  const int nnz = a.t_rowptr[a.N];
+  const int64_t p0l = w * DEC_CHUNK;
+  if (p0l >= nnz) return;
+  const int p0 = (int)p0l;
+  const int p1 = p0 + DEC_CHUNK < nnz ? p0 + DEC_CHUNK : nnz;
+  const int fl = lane % LPR;
+  const bool fl_ok = 4 * fl < a.D;
+  const int r0 = dec_row_of(a.t_rowptr, a.N, p0);
+  const int r1 = dec_row_of(a.t_rowptr, a.N, p1 - 1);
+  auto piece = [&](int lo, int hi, int slot) {
+    int rc, rp;
+    dec_bwd_raw(a, lo, hi, lane, rc, rp);
+    const DecBwdBatch b = dec_bwd_resolve(a, lo, hi, lane, rc, rp);
+    float4 s1, s2;
+    dec_bwd_seg<LPR>(a, lo, hi, lane, fl_ok, b, s1, s2);
+    if (lane < LPR && fl_ok) {
+      float* o = a.partial + ((size_t)w * 2 + slot) * 2 * (4 * LPR) + 4 * fl;
+      *reinterpret_cast<float4*>(o) = s1;
+      *reinterpret_cast<float4*>(o + 4 * LPR) = s2;
+    }
+  };
+  if (a.t_rowptr[r0 + 1] - a.t_rowptr[r0] > DEC_CHUNK) piece(p0, a.t_rowptr[r0 + 1] < p1 ? a.t_rowptr[r0 + 1] : p1, 0);
+  if (r1 != r0 && a.t_rowptr[r1 + 1] - a.t_rowptr[r1] > DEC_CHUNK) piece(a.t_rowptr[r1], p1, 1);
+}
+
+// rows: scheduling as the forward kernel (per-XCD in-order queue, every wave draws DEC_ROWS consecutive rows).  Inside a
+// draw the loads that feed later rows are issued BEFORE the current row's gathers - dependent half of row i+1 (its
+// inputs landed an iteration ago), raw half of row i+2, then the gathers of row i - so one wait covers all three.
+template <int LPR>
+__global__ __launch_bounds__(DEC_WAVES * 64) void dec_bwd_rows_kernel(DecBwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int fl = lane % LPR;
+  const bool fl_ok = 4 * fl < a.D;
+  const int xcd = blockIdx.x & 7;
+  const int64_t N = a.N;
+  const int64_t nnz = a.t_rowptr[N];
+  const int64_t r_begin = xcd == 0 ? 0 : dec_row_lower_bound(a.t_rowptr, N, nnz * xcd / 8);
+  const int64_t r_end = xcd == 7 ? N : dec_row_lower_bound(a.t_rowptr, N, nnz * (xcd + 1) / 8);
+  unsigned int* q = a.queue + xcd * 32;
+  const float gp = a.gscale[0], gn = a.gscale[1];
+  unsigned int dv = 0;
+  if (lane == 0) dv = atomicAdd(q, (unsigned)DEC_ROWS);
+  for (;;) {
+    const int64_t base_r = r_begin + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
+    if (base_r >= r_end) break;
+    if (lane == 0) dv = atomicAdd(q, (unsigned)DEC_ROWS);
+    const int cnt = r_end - base_r < DEC_ROWS ? (int)(r_end - base_r) : DEC_ROWS;
+    int rpv = 0;
+    if (lane <= cnt) rpv = a.t_rowptr[base_r + lane];
+    auto lo_of = [&](int i) { return __builtin_amdgcn_readlane(rpv, i < cnt ? i : cnt); };
+    auto hi_of = [&](int i) { return __builtin_amdgcn_readlane(rpv, i < cnt ? i + 1 : cnt); };
+    auto short_row = [&](int i) { return hi_of(i) - lo_of(i) <= DEC_CHUNK; };
+    // fill: row 0 resolved, row 1 raw
+    int rc0, rp0, rc1 = 0, rp1 = 0;
+    dec_bwd_raw(a, lo_of(0), short_row(0) ? hi_of(0) : lo_of(0), lane, rc0, rp0);
+    if (cnt > 1) dec_bwd_raw(a, lo_of(1), short_row(1) ? hi_of(1) : lo_of(1), lane, rc1, rp1);
+    DecBwdBatch cur = dec_bwd_resolve(a, lo_of(0), short_row(0) ? hi_of(0) : lo_of(0), lane, rc0, rp0);
+    for (int i = 0; i < cnt; ++i) {
+      const int p_lo = lo_of(i), p_hi = hi_of(i);
+      DecBwdBatch nxt = cur;
+      if (i + 1 < cnt) nxt = dec_bwd_resolve(a, lo_of(i + 1), short_row(i + 1) ? hi_of(i + 1) : lo_of(i + 1), lane, rc1, rp1);
+      int rc2 = 0, rp2 = 0;
+      if (i + 2 < cnt) dec_bwd_raw(a, lo_of(i + 2), short_row(i + 2) ? hi_of(i + 2) : lo_of(i + 2), lane, rc2, rp2);
+      const int64_t r = base_r + i;
+      float4 s1, s2;
+      if (p_hi - p_lo <= DEC_CHUNK) {
+        dec_bwd_seg<LPR>(a, p_lo, p_hi, lane, fl_ok, cur, s1, s2);
+      } else {
+        s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        s2 = s1;
+        const int c_lo = p_lo / DEC_CHUNK, c_hi = (p_hi - 1) / DEC_CHUNK;
+        if (lane < LPR && fl_ok) {
+          for (int c = c_lo; c <= c_hi; ++c) {  // pieces in ascending position order
+            const int slot = (c == c_lo && p_lo != c * DEC_CHUNK) ? 1 : 0;
+            const float* o = a.partial + ((size_t)c * 2 + slot) * 2 * (4 * LPR) + 4 * fl;
+            const float4 t1 = *reinterpret_cast<const float4*>(o);
+            const float4 t2 = *reinterpret_cast<const float4*>(o + 4 * LPR);
+            s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+            s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+          }
+        }
+      }
+      if (lane < LPR && fl_ok) {
+        if (a.grow_pos) {
+          const float4 A = *reinterpret_cast<const float4*>(a.grow_pos + r * a.ldg + 4 * fl);
+          const float4 B = *reinterpret_cast<const float4*>(a.grow_neg + r * a.ldg + 4 * fl);
+          s1.x += A.x; s1.y += A.y; s1.z += A.z; s1.w += A.w;
+          s2.x += B.x; s2.y += B.y; s2.z += B.z; s2.w += B.w;
+        }
+        s1.x *= gp; s1.y *= gp; s1.z *= gp; s1.w *= gp;
+        s2.x *= gn; s2.y *= gn; s2.z *= gn; s2.w *= gn;
+        float4 o;  // (second pass) + (first pass), as the accumulating two-pass form rounds it
+        o.x = s2.x + s1.x; o.y = s2.y + s1.y; o.z = s2.z + s1.z; o.w = s2.w + s1.w;
+        *reinterpret_cast<float4*>(a.dz + r * a.lddz + 4 * fl) = o;
+      }
+      cur = nxt;
+      rc1 = rc2;
+      rp1 = rp2;
     }
   }
 }
@@ -418,14 +642,18 @@ extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
   if (N <= 0 || nnz < 0 || D <= 0) return 0;
   const size_t a = DEC_QUEUE_BYTES + ceeg_ws_part((size_t)(N / DEC_ROWS + 16) * 3, 4);
   const size_t a0 = ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
+  const size_t nchunk = (size_t)((nnz + DEC_CHUNK - 1) / DEC_CHUNK);
+  const size_t c0 = DEC_QUEUE_BYTES + ceeg_ws_part((nchunk + 1) * 2 * 2 * 4 * (size_t)dec_lpr(D), 4);  // fused backward: queue + long-row partials
   const size_t b = ceeg_spmm_ws_bytes(N, nnz, D);
-  return (a > b ? a : b) > a0 ? (a > b ? a : b) : a0;
+  const size_t m = (a > b ? a : b) > a0 ? (a > b ? a : b) : a0;
+  return m > c0 ? m : c0;
 }
 
 extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
-                                      float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
+                                      float* coef_pos, float* coef_neg, int coef_stride, float* grow_pos, float* grow_neg, int64_t ldg,
                                       float* sums, void* ws, size_t ws_bytes, void* stream) {
+  if (coef_stride != 1 && coef_stride != 2) return CEEG_EINVAL;
   if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
   if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
   if (!z || !rowptr || !sums || N <= 0 || nnz < 0 || D <= 0 || (nnz > 0 && (!col || !coef_pos || !coef_neg))) return CEEG_EINVAL;
@@ -447,10 +675,10 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   case L:                                                                                                                             \
     if (grow_pos)                                                                                                                     \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
-                         sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
+                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, part);                                                   \
     else                                                                                                                              \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
-                         sig_b, sig_mod, coef_pos, coef_neg, grow_pos, grow_neg, ldg, queue, part);                                                   \
+                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, part);                                                   \
     break;
   switch (lpr) {
     CEEG_DEC_CASE(1)
@@ -472,7 +700,7 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
 extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                                       const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
-                                      const float* coef_pos, const float* coef_neg, const float* grow_pos,
+                                      const float* coef_pos, const float* coef_neg, int coef_stride, const float* grow_pos,
                                       const float* grow_neg, int64_t ldg, const float* gscale, float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                                       void* ws, size_t ws_bytes, void* stream) {
   if (!z || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0) return CEEG_EINVAL;
@@ -484,18 +712,58 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
   if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
-  if (grow_pos) {
-    // the forward already holds the row-side sums (terms (1) and (3) below); two transposed passes finish the job:
-    //   dz[n]  = gp * (grow_pos[n] + sum_{q in trow n} cp[tperm q] z[tcol q])
-    //   dz[n] += gn * (grow_neg[n] + sum_{q in trow n} cn[tperm q] z[sigma(tcol q)])
-    CeegSpmmEx t2; t2.mod = sig_mod; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg; t2.xidx = zidx;
+  if (coef_stride != 1 && coef_stride != 2) return CEEG_EINVAL;
+  const char* two_pass_env = getenv("CEEG_DEC_BWD_TWO_PASS");  // checker's switch: the same sums as two SpMM passes
+  if (grow_pos && two_pass_env && two_pass_env[0] == '1') {
+    CeegSpmmEx t2; t2.mod = sig_mod; t2.scale = gscale + 0; t2.max_row_nnz = max_trow_nnz; t2.addend = grow_pos; t2.ld_add = ldg;
+    t2.xidx = zidx; t2.val_stride = coef_stride;
     rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, t2);
     if (rc != CEEG_OK) return rc;
     CeegSpmmEx t4 = t2; t4.scale = gscale + 1; t4.col_a = sig_a; t4.col_b = sig_b; t4.addend = grow_neg;
     return ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, t4);
   }
+  if (grow_pos) {
+    // the forward already holds the row-side sums (terms (1) and (3) below); ONE kernel pair adds both transposed terms:
+    //   dz[n] = gn * (grow_neg[n] + sum_{q in trow n} cn[tperm q] z[sigma(tcol q)]) + gp * (grow_pos[n] + sum_q cp[tperm q] z[tcol q])
+    if ((D % 4) != 0 || D > 256 || (ldz % 4) != 0 || ldz < D || (lddz % 4) != 0 || lddz < D || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31))
+      return CEEG_EUNSUPPORTED;
+    if (!ceeg_aligned(z, 16) || !ceeg_aligned(dz, 16) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EINVAL;
+    const int lpr = dec_lpr(D);
+    DecBwdArgs a;
+    a.t_rowptr = t_rowptr; a.t_col = t_col; a.t_perm = t_perm; a.zidx = zidx;
+    a.coef_pos = coef_pos; a.coef_neg = coef_neg; a.z = z; a.grow_pos = grow_pos; a.grow_neg = grow_neg; a.gscale = gscale;
+    a.dz = dz;
+    a.queue = static_cast<unsigned int*>(ws);
+    a.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + DEC_QUEUE_BYTES);
+    a.ldz = ldz; a.ldg = ldg; a.lddz = lddz; a.N = N; a.sig_a = sig_a; a.sig_b = sig_b; a.sig_mod = sig_mod;
+    a.cstride = coef_stride; a.D = D;
+    if (hipMemsetAsync(a.queue, 0, DEC_QUEUE_BYTES, st) != hipSuccess) return CEEG_ELAUNCH;
+    const int64_t nchunk = (nnz + DEC_CHUNK - 1) / DEC_CHUNK;
+    const bool has_long = nchunk > 0 && !(max_trow_nnz >= 0 && max_trow_nnz <= DEC_CHUNK);
+    int64_t per_xcd = (N + 8 * DEC_WAVES * DEC_ROWS - 1) / (8 * DEC_WAVES * DEC_ROWS);
+    if (per_xcd > DEC_BLOCKS_PER_XCD) per_xcd = DEC_BLOCKS_PER_XCD;
+#define CEEG_DECB_CASE(L)                                                                                                         \
+  case L:                                                                                                                         \
+    if (has_long)                                                                                                                 \
+      hipLaunchKernelGGL(dec_bwd_long_kernel<L>, dim3((unsigned)((nchunk + DEC_WAVES - 1) / DEC_WAVES)), dim3(DEC_WAVES * 64), 0, st, a); \
+    hipLaunchKernelGGL(dec_bwd_rows_kernel<L>, dim3((unsigned)(8 * per_xcd)), dim3(DEC_WAVES * 64), 0, st, a);                     \
+    break;
+    switch (lpr) {
+      CEEG_DECB_CASE(1)
+      CEEG_DECB_CASE(2)
+      CEEG_DECB_CASE(4)
+      CEEG_DECB_CASE(8)
+      CEEG_DECB_CASE(16)
+      CEEG_DECB_CASE(32)
+      CEEG_DECB_CASE(64)
+      default: return CEEG_EUNSUPPORTED;
+    }
+#undef CEEG_DECB_CASE
+    CEEG_CHECK_LAUNCH();
+    return CEEG_OK;
+  }
   // (1) n as dst of positives:            dz[n]  = gp * sum_{p in row n} cp[p] z[col p]
-  CeegSpmmEx e1; e1.mod = sig_mod; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz; e1.xidx = zidx;
+  CeegSpmmEx e1; e1.mod = sig_mod; e1.scale = gscale + 0; e1.max_row_nnz = max_row_nnz; e1.xidx = zidx; e1.val_stride = coef_stride;
   CeegSpmmEx e2 = e1; e2.max_row_nnz = max_trow_nnz;
   rc = ceeg_spmm_launch(rowptr, col, coef_pos, nullptr, z, ldz, N, nnz, D, nullptr, 0, 0, dz, lddz, ws, ws_bytes, st, e1);
   if (rc != CEEG_OK) return rc;
@@ -503,11 +771,11 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_pos, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e2);
   if (rc != CEEG_OK) return rc;
   // (3) n = sigma(r) as negative endpoint: dz[sigma(r)] += gn * sum_{p in row r} cn[p] z[col p]
-  CeegSpmmEx e3; e3.mod = sig_mod; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz; e3.xidx = zidx;
+  CeegSpmmEx e3; e3.mod = sig_mod; e3.scale = gscale + 1; e3.row_a = sig_a; e3.row_b = sig_b; e3.max_row_nnz = max_row_nnz; e3.xidx = zidx; e3.val_stride = coef_stride;
   rc = ceeg_spmm_launch(rowptr, col, coef_neg, nullptr, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e3);
   if (rc != CEEG_OK) return rc;
   // (4) n as src of negatives:            dz[n] += gn * sum_{q in trow n} cn[tperm q] z[sigma(tcol q)]
-  CeegSpmmEx e4; e4.mod = sig_mod; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz; e4.xidx = zidx;
+  CeegSpmmEx e4; e4.mod = sig_mod; e4.scale = gscale + 1; e4.col_a = sig_a; e4.col_b = sig_b; e4.max_row_nnz = max_trow_nnz; e4.xidx = zidx; e4.val_stride = coef_stride;
   rc = ceeg_spmm_launch(t_rowptr, t_col, coef_neg, t_perm, z, ldz, N, nnz, D, nullptr, 0, 1, dz, lddz, ws, ws_bytes, st, e4);
   return rc;
 }

@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
     my_c = col[base + lane];
     if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)ceeg_block_affine((int64_t)my_c, ex.col_a, ex.col_b, ex.mod);
     if (ex.xidx) my_c = ex.xidx[my_c];  // X is a table: node c's row is X[xidx[c]]
-    my_v = vperm ? val[vperm[base + lane]] : val[base + lane];
+    my_v = val[(int64_t)(vperm ? vperm[base + lane] : base + lane) * ex.val_stride];
   }
 }
 

@@ -422,19 +422,19 @@ class _FusedDecoder(torch.autograd.Function):
             src, sidx = z.contiguous(), None
         z = src
         p = graph.dec
-        cp = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
-        cn = torch.empty(max(p.nnz, 1), dtype=torch.float32, device=z.device)[: p.nnz]
+        coef = torch.empty(max(p.nnz, 1), 2, dtype=torch.float32, device=z.device)  # (d pos / dv, d neg / dv) per entry, interleaved
+        cp, cn = coef[:, 0], coef[:, 1]
         sums = torch.empty(3, dtype=torch.float32, device=z.device)
         # with a gradient wanted, the forward also leaves the row-side halves of dz (two [N, D] tables)
         grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         with _lib.timed("decoder_fwd"):
             _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
-                                                cp.data_ptr(), cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
+                                                cp.data_ptr(), cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
         ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
-        ctx.save_for_backward(z, cp, cn, inv)
+        ctx.save_for_backward(z, coef, inv)
         ctx.sidx, ctx.shape = sidx, (N, D)
         ctx.graph, ctx.sig = graph, (a, b, ainv, mod)
         ctx.mark_non_differentiable(sums)
@@ -442,7 +442,8 @@ class _FusedDecoder(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _gs):
-        z, cp, cn, inv = ctx.saved_tensors
+        z, coef, inv = ctx.saved_tensors
+        cp, cn = coef[:, 0], coef[:, 1]
         L = _lib.lib()
         N, D = ctx.shape
         p = ctx.graph.dec
@@ -455,7 +456,7 @@ class _FusedDecoder(torch.autograd.Function):
         with _lib.timed("decoder_bwd"):
             _lib.check(L.ceeg_decoder_fused_bwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), p.t_rowptr.data_ptr(),
                                                 p.t_col.data_ptr(), p.t_perm.data_ptr(), N, p.nnz, D, a, b, ainv, mod, cp.data_ptr(),
-                                                cn.data_ptr(), _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
+                                                cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                 gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
                                                 _lib.stream()), "ceeg_decoder_fused_bwd")
         ctx.grow = None

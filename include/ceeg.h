@@ -163,7 +163,9 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
  *   m = nodes per graph keeps the negatives of a block-diagonal batch (equal-sized graphs) inside their graph.
  *   A negative is INVALID (masked out, coef 0) when col[p]==sigma(r) or (col[p] -> sigma(r)) is an edge
  *   (binary search in row sigma(r), rows being src-sorted).
- * One gather of z[col[p]] serves both dots.  Outputs coef_pos[nnz], coef_neg[nnz] (unscaled d term/dv),
+ * One gather of z[col[p]] serves both dots.  Outputs coef_pos[p*coef_stride], coef_neg[p*coef_stride] (unscaled d term/dv;
+ * coef_stride 1 = two dense arrays, 2 = one interleaved [nnz][2] array with coef_neg = coef_pos + 1, which lets the
+ * backward fetch a pair from one memory sector),
  * sums[0]=sum pos terms, sums[1]=sum valid neg terms, sums[2]=number of valid negatives (as float),
  * all written to `sums` (3 floats, device).  rowptr/col: CSR WITHOUT self-loops (ceeg_csr_build
  * self_loops=0).
@@ -177,7 +179,7 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
 size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
 int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
-                           float* coef_pos, float* coef_neg, float* grow_pos, float* grow_neg, int64_t ldg,
+                           float* coef_pos, float* coef_neg, int coef_stride, float* grow_pos, float* grow_neg, int64_t ldg,
                            float* sums, void* ws, size_t ws_bytes, void* stream);
 /* Backward of the fused decoder: dz[n] = gp * (pos terms) + gn * (neg terms) where gp/gn are read from
  * the device (gscale[0], gscale[1]: upstream grad times 1/E_pos resp. 1/n_valid_neg).
@@ -186,11 +188,12 @@ int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, con
  *         + sum_{p in row sigma^-1(n)} gn*cn[p] z[col p]       (n as negative endpoint sigma(r))
  *         + sum_{q in trow n} gn*cn[tperm q] z[sigma(tcol q)]  (n as src of negatives)
  * sig_ainv = a^-1 mod N.  With grow_pos/grow_neg from the forward (both non-NULL) the first and third sums are
- * taken from those tables and only the two transposed passes run; with NULL all four passes run. */
+ * taken from those tables and ONE fused kernel adds both transposed sums (bitwise equal to running them as two SpMM
+ * passes); with NULL all four passes run. */
 int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                            const int32_t* t_rowptr, const int32_t* t_col, const int32_t* t_perm,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_ainv, int64_t sig_mod,
-                           const float* coef_pos, const float* coef_neg, const float* grow_pos,
+                           const float* coef_pos, const float* coef_neg, int coef_stride, const float* grow_pos,
                            const float* grow_neg, int64_t ldg, const float* gscale,
                            float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                            void* ws, size_t ws_bytes, void* stream);

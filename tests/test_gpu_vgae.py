@@ -239,6 +239,17 @@ def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e):
         (r2 * 0.7).backward()
         assert torch.equal(r1, r2) and torch.equal(s1, s2)
         assert torch.equal(x1.grad, x2.grad)
+    # the fused two-sum backward kernel == the same sums run as two SpMM passes, bit for bit (hub rows included)
+    import os
+    grads = []
+    for env in ("0", "1"):
+        os.environ["CEEG_DEC_BWD_TWO_PASS"] = env
+        x3 = zq.clone().requires_grad_(True)
+        r3, _ = _FusedDecoder.apply(x3, g, a_, b_, ainv, True, None, W, idx)
+        (r3 * 0.7).backward()
+        grads.append(x3.grad.clone())
+    os.environ.pop("CEEG_DEC_BWD_TWO_PASS")
+    assert torch.equal(grads[0], grads[1])
 
 
 def test_config1_plumbing_csv_to_training(tmp_path):
