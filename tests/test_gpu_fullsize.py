@@ -1,0 +1,110 @@
+"""BASELINE.json's full sizes through size-independent properties (the oracle cannot run these in seconds):
+config 2 (1 M nodes / 16 M edges): CSR order and checksums, SpMM adjointness <A x, y> = <x, A^T y>, linearity,
+bitwise reproducibility, fused decoder determinism + gradient consistency with the four-pass form;
+config 3 (4 Mi x 512 x 256): z_q rows are codebook rows, histogram sums to B, idempotence (fp32), reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def config2():
+    from causal_eeg_vae_amd import EventGraph
+    from causal_eeg_vae_amd.synth import synth_event_graph
+    N, E = 1_000_000, 16_000_000
+    ei = synth_event_graph(N, E, seed=3, device="cuda")
+    g = EventGraph(ei, N)
+    g.dec
+    return N, E, ei, g
+
+
+def test_config2_csr_sorted_and_checksums(config2):
+    N, E, ei, g = config2
+    for pair, loops in ((g.gcn, N), (g.dec, 0)):
+        assert pair.nnz == E + loops
+        rp = pair.rowptr.long()
+        assert int(rp[0]) == 0 and int(rp[-1]) == pair.nnz and bool((rp[1:] >= rp[:-1]).all())
+        rows = torch.repeat_interleave(torch.arange(N, device="cuda"), rp[1:] - rp[:-1])
+        key = rows * N + pair.col.long()
+        assert bool((key[1:] > key[:-1]).all())            # strictly ascending (dst, src): sorted, no duplicates
+        # checksum of checksums: the multiset of (src, dst) pairs is the input's (+ one loop per node)
+        want = (ei[1] * N + ei[0]).sum() + (loops and (torch.arange(N, device="cuda") * (N + 1)).sum())
+        assert int(key.sum()) == int(want)
+        # transpose holds the same entries grouped by source, and t_perm points back at them
+        trp = pair.t_rowptr.long()
+        trow = torch.repeat_interleave(torch.arange(N, device="cuda"), trp[1:] - trp[:-1])
+        assert torch.equal(rows[pair.t_perm.long()], pair.t_col.long()) and torch.equal(pair.col.long()[pair.t_perm.long()], trow)
+
+
+@pytest.mark.parametrize("F", [128, 256])
+def test_config2_spmm_adjoint_linear_reproducible(config2, F):
+    from causal_eeg_vae_amd.models import _spmm
+    N, E, ei, g = config2
+    gen = torch.Generator(device="cuda").manual_seed(F)
+    x = torch.randn(N, F, device="cuda", generator=gen)
+    y = torch.randn(N, F, device="cuda", generator=gen)
+    A = lambda v: _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, v, N, max_row=g.gcn.max_row)
+    AT = lambda v: _spmm(g.gcn.t_rowptr, g.gcn.t_col, g.gcn_tval, None, v, N, max_row=g.gcn.max_trow)
+    ax, aty = A(x), AT(y)
+    assert torch.equal(ax, A(x)) and torch.equal(aty, AT(y))
+    lhs, rhs = (ax.double() * y.double()).sum(), (x.double() * aty.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * float((ax.double().abs() * y.double().abs()).sum())
+    # the permuted-value form of the transposed pass gives the same numbers as the pre-permuted stream
+    assert torch.equal(aty, _spmm(g.gcn.t_rowptr, g.gcn.t_col, g.gcn_val, g.gcn.t_perm, y, N))
+    torch.testing.assert_close(A(2 * x + y), 2 * ax + A(y), rtol=1e-4, atol=1e-4)
+    # rows of A_hat sum to <= 1-ish positive numbers: A 1 = D^-1/2 (A+I) D^-1/2 1 is finite and positive
+    ones = A(torch.ones(N, F, device="cuda"))
+    assert bool(torch.isfinite(ones).all()) and float(ones.min()) > 0
+
+
+def test_config2_fused_decoder(config2):
+    from causal_eeg_vae_amd import sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    N, E, ei, g = config2
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    W = torch.randn(512, 128, device="cuda", generator=gen) * 0.2
+    idx = torch.randint(0, 512, (N,), device="cuda", generator=gen, dtype=torch.int32)
+    zq = W[idx.long()]
+    a, b, ainv = sigma_params(N, 0, 11)
+    outs = []
+    for kw in (dict(row_sums=True, table=True), dict(row_sums=True, table=True), dict(row_sums=True, table=False), dict(row_sums=False, table=False)):
+        x = zq.clone().requires_grad_(True)
+        args = (W, idx) if kw["table"] else (None, None)
+        rec, sums = _FusedDecoder.apply(x, g, a, b, ainv, kw["row_sums"], None, *args)
+        rec.backward()
+        outs.append((rec.detach(), sums.detach(), x.grad))
+    for o in outs[1:3]:                                     # rerun and expanded-matrix form: bitwise
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    assert torch.equal(outs[3][0], outs[0][0])              # four-pass backward: same loss, gradient to rounding
+    torch.testing.assert_close(outs[3][2], outs[0][2], rtol=1e-4, atol=1e-9)
+    n_valid = int(outs[0][1][2])
+    assert 0.99 * E < n_valid <= E                          # few permuted pairs collide with edges on a sparse graph
+    assert float(outs[0][0]) > 0
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_config3_vq_properties(dt):
+    from causal_eeg_vae_amd import VectorQuantizer
+    B, n_e, D = 4 * 1024 * 1024, 512, 256
+    torch.manual_seed(0)
+    vq = VectorQuantizer(n_e, D, 0.25, return_one_hot=False).cuda()
+    with torch.no_grad():
+        vq.embedding.weight.normal_()
+        z = torch.randn(B, D, device="cuda").to(dt)
+        l1, q1, p1, _, i1 = vq(z)
+        l2, q2, p2, _, i2 = vq(z)
+        assert torch.equal(i1, i2) and torch.equal(l1, l2) and torch.equal(p1, p2)
+        assert i1.dtype == torch.int64 and tuple(i1.shape) == (B, 1)
+        assert int(i1.min()) >= 0 and int(i1.max()) < n_e
+        assert int(torch.bincount(i1[:, 0], minlength=n_e).sum()) == B
+        for lo in range(0, B, B // 4):                      # z_q rows ARE (rounded) codebook rows
+            sl = slice(lo, lo + B // 4)
+            assert torch.equal(q1[sl], vq.embedding.weight[i1[sl, 0]].to(dt))
+        del q2, l2, p2, i2
+        if dt == torch.float32:
+            _, _, _, _, i3 = vq(q1)                         # idempotence: a codebook row is its own nearest code
+            assert torch.equal(i3, i1)
+        ppl = float(p1)
+        assert 1.0 <= ppl <= n_e
