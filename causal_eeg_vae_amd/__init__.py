@@ -6,5 +6,5 @@ from ._lib import CeegError, LIB_PATH, lib  # noqa: F401
 from .quantizer import VectorQuantizer  # noqa: F401
 from .models import (  # noqa: F401
     MAX_LOGSTD, CsrPair, EventGraph, GCNConv, InnerProductDecoder, VariationalGCNEncoder, VGAE, VGAEVQ,
-    ConditionalVGAEVQ, negative_sampling, sigma_params,
+    ConditionalVGAEVQ, GATConv, negative_sampling, sigma_params,
 )

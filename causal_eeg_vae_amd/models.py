@@ -596,3 +596,92 @@ class ConditionalVGAEVQ(nn.Module):
         rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
         loss = rec + kl / N + vq_loss
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
+
+
+# ==================================================================================================
+# GATConv (the graph layer the reference actually instantiates: scripts/models.py:106)
+# ==================================================================================================
+class _GATAggregate(torch.autograd.Function):
+    """out[i, h] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * xp[j, h, :] over the CSR row of i (self-loops in).
+    Softmax weights: ceeg_gat_softmax_fwd; aggregation and its transpose: ceeg_spmm_csr; attention backward:
+    ceeg_gat_attn_bwd + ceeg_segment_sum_perm.  One pass per head over column slices (no copies)."""
+
+    @staticmethod
+    def forward(ctx, xp, a_src, a_dst, pair, heads, slope):
+        _lib.require_cuda(xp)
+        L = _lib.lib()
+        xp, a_src, a_dst = xp.contiguous(), a_src.t().contiguous(), a_dst.t().contiguous()  # a_*: [H, N]
+        N, HC = xp.shape
+        C = HC // heads
+        w = torch.empty(heads, max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
+        out = torch.empty_like(xp)
+        for h in range(heads):
+            _lib.check(L.ceeg_gat_softmax_fwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), a_src[h].data_ptr(), a_dst[h].data_ptr(),
+                                              N, pair.nnz, float(slope), w[h].data_ptr(), _lib.stream()), "ceeg_gat_softmax_fwd")
+            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, out=out[:, h * C:(h + 1) * C], max_row=pair.max_row)
+        ctx.save_for_backward(xp, a_src, a_dst, w)
+        ctx.pair, ctx.heads, ctx.slope = pair, heads, float(slope)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xp, a_src, a_dst, w = ctx.saved_tensors
+        pair, heads, slope = ctx.pair, ctx.heads, ctx.slope
+        L = _lib.lib()
+        g = g.contiguous()
+        N, HC = xp.shape
+        C = HC // heads
+        dxp = torch.empty_like(xp)
+        d_asrc = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
+        d_adst = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
+        dl = torch.empty(max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
+        for h in range(heads):
+            gs, xs = g[:, h * C:(h + 1) * C], xp[:, h * C:(h + 1) * C]
+            _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, gs, N, out=dxp[:, h * C:(h + 1) * C], max_row=pair.max_trow)
+            _lib.check(L.ceeg_gat_attn_bwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), w[h].data_ptr(), a_src[h].data_ptr(),
+                                           a_dst[h].data_ptr(), gs.data_ptr(), gs.stride(0), xs.data_ptr(), xs.stride(0), N, pair.nnz, C,
+                                           slope, dl.data_ptr(), d_adst[h].data_ptr(), _lib.stream()), "ceeg_gat_attn_bwd")
+            _lib.check(L.ceeg_segment_sum_perm(pair.t_rowptr.data_ptr(), pair.t_perm.data_ptr(), dl.data_ptr(), N, d_asrc[h].data_ptr(),
+                                               _lib.stream()), "ceeg_segment_sum_perm")
+        return dxp, d_asrc.t(), d_adst.t(), None, None, None
+
+
+class GATConv(nn.Module):
+    """PyG-style GATConv(in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_self_loops=True,
+    bias=True) for one node set: x' = x W^T;  alpha_ij = softmax_j(leaky_relu(<x'_j, att_src> + <x'_i, att_dst>));
+    out_i = sum_j alpha_ij x'_j (+ bias).  State-dict keys `lin_src.weight` (shared source/target transform),
+    `att_src`, `att_dst` [1, heads, out], `bias`.  out_channels must be a multiple of 4 and <= 256 per head."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_self_loops=True, bias=True):
+        super().__init__()
+        if out_channels % 4 or out_channels > 256:
+            raise ValueError("out_channels must be a multiple of 4 and <= 256")
+        if not add_self_loops:
+            raise NotImplementedError("the CSR built for attention always carries one self-loop per node")
+        self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, int(heads), bool(concat)
+        self.negative_slope = float(negative_slope)
+        self.lin_src = _Lin(in_channels, heads * out_channels)
+        self.att_src = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_dst = nn.Parameter(torch.empty(1, heads, out_channels))
+        glorot_(self.att_src.data.view(heads, out_channels))
+        glorot_(self.att_dst.data.view(heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels)) if bias else None
+
+    @staticmethod
+    def attention_graph(edge_index, num_nodes):
+        """CSR pair for attention: self-loops of the input removed, one fresh self-loop per node added (PyG)."""
+        keep = edge_index[0] != edge_index[1]
+        return CsrPair(edge_index[:, keep], num_nodes, self_loops=True)
+
+    def forward(self, x, graph):
+        N = x.shape[0]
+        pair = graph if isinstance(graph, CsrPair) else self.attention_graph(graph.edge_index if isinstance(graph, EventGraph) else graph, N)
+        H, C = self.heads, self.out_channels
+        xp = _Linear.apply(x, self.lin_src.weight, None, False)                     # [N, H*C]
+        xv = xp.view(N, H, C)
+        a_src = (xv * self.att_src).sum(dim=-1)                                     # [N, H]
+        a_dst = (xv * self.att_dst).sum(dim=-1)
+        out = _GATAggregate.apply(xp, a_src, a_dst, pair, H, self.negative_slope)
+        if not self.concat:
+            out = out.view(N, H, C).mean(dim=1)
+        return out if self.bias is None else out + self.bias

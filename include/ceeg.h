@@ -210,6 +210,25 @@ int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ld
                          float* colsum, void* ws, size_t ws_bytes, void* stream);
 int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N1  GATConv attention (upstream PyG GATConv, instantiated by the reference at scripts/models.py:106), one head per
+ * call.  rowptr/col: CSR grouped by destination with one self-loop per node (ceeg_csr_build self_loops=1 on the
+ * edges without their own self-loops, as PyG's remove_self_loops + add_self_loops).
+ *   forward : e[p] = leaky_relu(a_src[col p] + a_dst[row p], slope);  w[p] = exp(e[p] - max_row) / (sum_row + 1e-16)
+ *             (PyG utils.softmax); the aggregation out[i] = sum_p w[p] xp[col p] is ceeg_spmm_csr with val = w.
+ *   backward: dw[p] = <g[row p], xp[col p]>;  de[p] = w[p] (dw[p] - sum_k w[k] dw[k]);
+ *             dl[p] = de[p] * (a_src[col p] + a_dst[row p] > 0 ? 1 : slope);  d_adst[i] = sum_{p in row i} dl[p];
+ *             d_asrc[j] = sum of dl over the entries whose source is j = ceeg_segment_sum_perm over the transposed CSR.
+ * g, xp: [N, ld] fp32 with C columns (C % 4 == 0, C <= 256; a head's column slice of a wider matrix is fine). */
+int ceeg_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
+                         int64_t N, int64_t nnz, float slope, float* w, void* stream);
+int ceeg_gat_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* w, const float* a_src,
+                      const float* a_dst, const float* g, int64_t ldg, const float* xp, int64_t ldx, int64_t N,
+                      int64_t nnz, int C, float slope, float* dl, float* d_adst, void* stream);
+/* out[r] = sum_{q in [t_rowptr[r], t_rowptr[r+1])} v[t_perm[q]]  (t_perm NULL: v[q]); fixed-order wave sums. */
+int ceeg_segment_sum_perm(const int32_t* t_rowptr, const int32_t* t_perm, const float* v, int64_t N,
+                          float* out, void* stream);
+
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
  * when src==dst or src->dst is an edge of the given CSR (rows=dst, src-sorted), up to 16 attempts; a

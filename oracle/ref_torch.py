@@ -248,3 +248,34 @@ class RefVGAEVQ(nn.Module):
         rec = pos + nterm.mean()
         loss = rec + kl / x.shape[0] + vq_loss
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, mu=mu, logstd=logstd)
+
+
+class RefGATConv(nn.Module):
+    """Upstream PyG GATConv (heads, concat, negative_slope 0.2, add_self_loops, bias; dropout 0), written out:
+    x' = lin_src(x) -> [N,H,C]; a_s = <x', att_src>, a_d = <x', att_dst>; self-loops of the input removed and one per
+    node added; alpha = softmax over incoming edges of leaky_relu(a_s[src] + a_d[dst]) with PyG's
+    exp(e - max) / (sum + 1e-16); out = sum alpha * x'[src] at dst; concat (or mean over heads) + bias."""
+
+    def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2):
+        super().__init__()
+        self.heads, self.out_channels, self.concat, self.negative_slope = heads, out_channels, concat, negative_slope
+        self.lin_src = _Lin(in_channels, heads * out_channels)
+        self.att_src = nn.Parameter(torch.randn(1, heads, out_channels) * 0.3)
+        self.att_dst = nn.Parameter(torch.randn(1, heads, out_channels) * 0.3)
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels if concat else out_channels))
+
+    def forward(self, x, edge_index):
+        N, H, C = x.shape[0], self.heads, self.out_channels
+        xp = (x @ self.lin_src.weight.t()).view(N, H, C)
+        a_s, a_d = (xp * self.att_src).sum(-1), (xp * self.att_dst).sum(-1)
+        keep = edge_index[0] != edge_index[1]
+        ar = torch.arange(N)
+        src, dst = torch.cat([edge_index[0][keep], ar]), torch.cat([edge_index[1][keep], ar])
+        e = torch.nn.functional.leaky_relu(a_s[src] + a_d[dst], self.negative_slope)            # [E, H]
+        m = torch.full((N, H), -float("inf"), dtype=x.dtype).scatter_reduce(0, dst[:, None].expand(-1, H), e, "amax", include_self=True)
+        ex = (e - m[dst]).exp()
+        den = torch.zeros(N, H, dtype=x.dtype).index_add_(0, dst, ex)
+        alpha = ex / (den[dst] + 1e-16)
+        out = torch.zeros(N, H, C, dtype=x.dtype).index_add_(0, dst, alpha[:, :, None] * xp[src])
+        out = out.reshape(N, H * C) if self.concat else out.mean(1)
+        return out + self.bias
