@@ -279,3 +279,22 @@ class RefGATConv(nn.Module):
         out = torch.zeros(N, H, C, dtype=x.dtype).index_add_(0, dst, alpha[:, :, None] * xp[src])
         out = out.reshape(N, H * C) if self.concat else out.mean(1)
         return out + self.bias
+
+
+def ref_global_attention(x, gate, batch, num_graphs):
+    """PyG GlobalAttention: softmax of the gate inside each graph (exp(g - max) / (sum + 1e-16)), weighted node sum."""
+    m = torch.full((num_graphs,), -float("inf"), dtype=x.dtype).scatter_reduce(0, batch, gate, "amax", include_self=True)
+    ex = (gate - m[batch]).exp()
+    den = torch.zeros(num_graphs, dtype=x.dtype).index_add_(0, batch, ex)
+    w = ex / (den[batch] + 1e-16)
+    return torch.zeros(num_graphs, x.shape[1], dtype=x.dtype).index_add_(0, batch, w[:, None] * x)
+
+
+def ref_graph_layer_norm(x, batch, num_graphs, weight=None, bias=None, eps=1e-5):
+    """PyG LayerNorm(mode='graph'): per-graph mean / biased variance over all nodes and channels."""
+    cnt = torch.bincount(batch, minlength=num_graphs).clamp(min=1).to(x.dtype) * x.shape[1]
+    mean = torch.zeros(num_graphs, dtype=x.dtype).index_add_(0, batch, x.sum(1)) / cnt
+    xc = x - mean[batch][:, None]
+    var = torch.zeros(num_graphs, dtype=x.dtype).index_add_(0, batch, (xc * xc).sum(1)) / cnt
+    out = xc / (var + eps).sqrt()[batch][:, None]
+    return out if weight is None else out * weight + bias

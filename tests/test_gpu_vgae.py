@@ -321,3 +321,41 @@ def test_gatconv_fwd_bwd_vs_oracle(N, E, Fi, C, H, concat):
         _close(p.grad, dict(ref.named_parameters())[name].grad, rtol=1e-3, atol_rel=1e-4)
     out2 = conv(b, ei.cuda())
     assert torch.equal(out, out2)
+
+
+def test_global_attention_and_graph_layernorm_vs_oracle():
+    """attention pooling and graph-mode LayerNorm over a collated batch (graphs of 1 .. 5000 nodes,
+    2048-wide features as the reference's conditioner uses: two 1024-column SpMM calls)."""
+    from causal_eeg_vae_amd.pool import GlobalAttention, GraphLayerNorm
+    from oracle import ref_torch
+    sizes = [1, 5000, 3, 70, 64, 65, 900]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, G = int(batch.shape[0]), len(sizes)
+    for F in (2048, 12):
+        torch.manual_seed(F)
+        gate_nn = torch.nn.Linear(F, 1)
+        x = torch.randn(N, F)
+        r = torch.randn(G, F)
+        a = x.clone().requires_grad_(True)
+        ref = ref_torch.ref_global_attention(a, gate_nn(a).view(-1), batch, G)
+        (ref * r).sum().backward()
+        gw = gate_nn.weight.grad.clone(); gate_nn.zero_grad()
+        pool = GlobalAttention(gate_nn).cuda()
+        b = x.clone().cuda().requires_grad_(True)
+        out = pool(b, batch.cuda(), G)
+        (out * r.cuda()).sum().backward()
+        _close(out, ref, rtol=1e-4, atol_rel=1e-5)
+        _close(b.grad, a.grad, rtol=1e-3, atol_rel=1e-4)
+        _close(pool.gate_nn.weight.grad, gw, rtol=1e-3, atol_rel=1e-4)
+        gate_nn.cpu()
+        ln = GraphLayerNorm(F).cuda()
+        with torch.no_grad():
+            ln.weight.normal_(); ln.bias.normal_()
+        a2 = x.clone().requires_grad_(True)
+        ref2 = ref_torch.ref_graph_layer_norm(a2, batch, G, ln.weight.detach().cpu(), ln.bias.detach().cpu())
+        (ref2 * x).sum().backward()
+        b2 = x.clone().cuda().requires_grad_(True)
+        out2 = ln(b2, batch.cuda(), G)
+        (out2 * x.cuda()).sum().backward()
+        _close(out2, ref2, rtol=1e-4, atol_rel=1e-5)
+        _close(b2.grad, a2.grad, rtol=1e-3, atol_rel=1e-4)
