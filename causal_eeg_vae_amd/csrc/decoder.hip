@@ -238,6 +238,109 @@ struct DecRow {     // everything a row needs before its gathers, fetched one ro
   float4 zr, zs;
 };
 
+// positions [p_lo, p_hi) of ONE row (a whole row, or a DEC_CHUNK-aligned piece of a hub row): dots, coefficients,
+// loss terms and - with GRAD - this piece's share of the row-side gradient sums, all into `st`.
+// (bc, bg): the lane's column / gather row of the first batch when the caller prefetched it (have_first).
+template <int LPR, bool GRAD>
+__device__ __forceinline__ void dec_fwd_segment(const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx,
+                                                const int32_t* __restrict__ col, int p_lo, int p_hi, int s_lo, int s_hi, int sr, int sc,
+                                                bool have_first, int bc, int bg, int lane, bool fl_ok, float* __restrict__ coef_pos,
+                                                float* __restrict__ coef_neg, int cstride, DecRowState& st) {
+  constexpr int G = 64 / LPR;
+  const int s_n = s_hi - s_lo;
+  for (int base = p_lo; base < p_hi; base += 64) {
+    const int n = p_hi - base < 64 ? p_hi - base : 64;
+    int my_c = bc, my_g = bg;
+    if (!have_first || base != p_lo) {
+      my_c = lane < n ? col[base + lane] : 0;
+      my_g = (zidx && lane < n) ? zidx[my_c] : my_c;
+    }
+    bool hit = false;
+    if (s_n <= 64) {
+      for (int t = 0; t < s_n; ++t) hit |= (my_c == __builtin_amdgcn_readlane(sc, t));
+    } else if (lane < n) {
+      hit = sorted_has(col, s_lo, s_hi, my_c);
+    }
+    const int my_valid = (lane < n && my_c != sr && !hit) ? 1 : 0;
+    const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
+    int i0 = 0;
+    for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+    const int rem = ns - i0;  // one round of the next power of two covers the tail
+    if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+    else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+    else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+  }
+  if constexpr (GRAD && G > 1) {
+#pragma unroll
+    for (int o = 32; o >= LPR; o >>= 1) {
+      st.ga.x += __shfl_xor(st.ga.x, o, 64); st.ga.y += __shfl_xor(st.ga.y, o, 64);
+      st.ga.z += __shfl_xor(st.ga.z, o, 64); st.ga.w += __shfl_xor(st.ga.w, o, 64);
+      st.gb.x += __shfl_xor(st.gb.x, o, 64); st.gb.y += __shfl_xor(st.gb.y, o, 64);
+      st.gb.z += __shfl_xor(st.gb.z, o, 64); st.gb.w += __shfl_xor(st.gb.w, o, 64);
+    }
+  }
+}
+
+__device__ __forceinline__ int dec_row_of(const int32_t* __restrict__ rowptr, int64_t N, int p) {
+  int64_t lo = 0, hi = N;  // last r in [0,N) with rowptr[r] <= p
+  while (hi - lo > 1) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (rowptr[mid] <= p) lo = mid; else hi = mid;
+  }
+  return (int)lo;
+}
+
+constexpr int DEC_CHUNK = 256;  // a row longer than this is cut at the GLOBAL positions k*DEC_CHUNK (as spmm.hip)
+
+// Pieces of hub rows (in-degree > DEC_CHUNK): wave w handles global positions [w*DEC_CHUNK, (w+1)*DEC_CHUNK) - one wave
+// per whole row would serialise a 1e5-entry row.  Each piece leaves its coefficients, its loss partial (slot
+// lslot0 + 2w + slot) and, with GRAD, its share of the row-side sums in `gpart`; the row kernel adds the shares in order.
+template <int LPR, bool GRAD>
+__global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_long_kernel(
+    const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx, const int32_t* __restrict__ rowptr,
+    const int32_t* __restrict__ col, int64_t N, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos,
+    float* __restrict__ coef_neg, int cstride, float* __restrict__ gpart, float* __restrict__ part, int64_t lslot0) {
+  const int lane = threadIdx.x & 63;
+  const int fl = lane % LPR;
+  const bool fl_ok = 4 * fl < D;
+  const int64_t w = (int64_t)blockIdx.x * DEC_WAVES + (threadIdx.x >> 6);
+  const int nnz = rowptr[N];
+  const int64_t p0l = w * DEC_CHUNK;
+  if (p0l >= nnz) return;
+  const int p0 = (int)p0l;
+  const int p1 = p0 + DEC_CHUNK < nnz ? p0 + DEC_CHUNK : nnz;
+  const int r0 = dec_row_of(rowptr, N, p0);
+  const int r1 = dec_row_of(rowptr, N, p1 - 1);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto piece = [&](int r, int lo, int hi, int slot) {
+    DecRowState st;
+    st.s_pos = st.s_neg = st.s_cnt = 0.f;
+    st.ga = zero4; st.gb = zero4; st.zr = zero4; st.zs = zero4;
+    const int sr = (int)ceeg_block_affine((int64_t)r, sig_a, sig_b, sig_mod);
+    const int s_lo = rowptr[sr], s_hi = rowptr[sr + 1];
+    const int sc = lane < s_hi - s_lo ? col[s_lo + lane] : 0;
+    if (fl_ok) {
+      st.zr = *reinterpret_cast<const float4*>(z + (int64_t)(zidx ? zidx[r] : r) * ldz + 4 * fl);
+      st.zs = *reinterpret_cast<const float4*>(z + (int64_t)(zidx ? zidx[sr] : sr) * ldz + 4 * fl);
+    }
+    dec_fwd_segment<LPR, GRAD>(z, ldz, zidx, col, lo, hi, s_lo, s_hi, sr, sc, false, 0, 0, lane, fl_ok, coef_pos, coef_neg, cstride, st);
+    if constexpr (GRAD) {
+      if (lane < LPR && fl_ok) {
+        float* o = gpart + ((size_t)w * 2 + slot) * 2 * (4 * LPR) + 4 * fl;
+        *reinterpret_cast<float4*>(o) = st.ga;
+        *reinterpret_cast<float4*>(o + 4 * LPR) = st.gb;
+      }
+    }
+    const float t0 = ceeg_wave_sum(st.s_pos), t1 = ceeg_wave_sum(st.s_neg), t2 = ceeg_wave_sum(st.s_cnt);
+    if (lane == 0) {
+      float* o = part + (size_t)(lslot0 + w * 2 + slot) * 3;
+      o[0] = t0; o[1] = t1; o[2] = t2;
+    }
+  };
+  if (rowptr[r0 + 1] - rowptr[r0] > DEC_CHUNK) piece(r0, p0, rowptr[r0 + 1] < p1 ? rowptr[r0 + 1] : p1, 0);
+  if (r1 != r0 && rowptr[r1 + 1] - rowptr[r1] > DEC_CHUNK) piece(r1, rowptr[r1], p1, 1);
+}
+
 // Row r of the dst-sorted CSR: positives (r, col p), negatives (col p, sigma(r)) - both share the gather of z[col p].
 // GRAD also leaves the row-side gradient sums (unscaled):  grow_pos[r] = sum_p cp[p] z[col p],
 // grow_neg[sigma(r)] = sum_p cn[p] z[col p]  (sigma is a bijection: every row of both tables is written once).
@@ -255,8 +358,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
     const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ col, int64_t N, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod, float* __restrict__ coef_pos, float* __restrict__ coef_neg, int cstride, float* __restrict__ grow_pos,
     float* __restrict__ grow_neg, int64_t ldg, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed */,
-    float* __restrict__ part) {
-  constexpr int G = 64 / LPR;
+    const float* __restrict__ gpart /* shares of hub rows */, float* __restrict__ part) {
   const int lane = threadIdx.x & 63;
   const int fl = lane % LPR;
   const bool fl_ok = 4 * fl < D;
@@ -294,7 +396,7 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
       w.s_hi = __builtin_amdgcn_readlane(sp_hi, i);
       w.sr = __builtin_amdgcn_readlane(sri, i);
       w.bc = 0; w.sc = 0; w.bg = 0; w.zr = zero4; w.zs = zero4;
-      if (w.p_lo != w.p_hi) {
+      if (w.p_lo != w.p_hi && w.p_hi - w.p_lo <= DEC_CHUNK) {
         if (lane < w.p_hi - w.p_lo) {
           w.bc = col[w.p_lo + lane];
           w.bg = zidx ? zidx[w.bc] : w.bc;
@@ -316,39 +418,23 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
       st.gb = zero4;
       st.zr = cur.zr;
       st.zs = cur.zs;
-      const int s_n = cur.s_hi - cur.s_lo;
-      for (int base = cur.p_lo; base < cur.p_hi; base += 64) {
-        const int n = cur.p_hi - base < 64 ? cur.p_hi - base : 64;
-        int my_c = cur.bc, my_g = cur.bg;
-        if (base != cur.p_lo) {
-          my_c = lane < n ? col[base + lane] : 0;
-          my_g = (zidx && lane < n) ? zidx[my_c] : my_c;
-        }
-        bool hit = false;
-        if (s_n <= 64) {
-          for (int t = 0; t < s_n; ++t) hit |= (my_c == __builtin_amdgcn_readlane(cur.sc, t));
-        } else if (lane < n) {
-          hit = sorted_has(col, cur.s_lo, cur.s_hi, my_c);
-        }
-        const int my_valid = (lane < n && my_c != cur.sr && !hit) ? 1 : 0;
-        const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
-        int i0 = 0;
-        for (; i0 + 4 <= ns; i0 += 4) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
-        const int rem = ns - i0;  // one round of the next power of two covers the tail
-        if (rem > 2) dec_round<LPR, 4, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
-        else if (rem == 2) dec_round<LPR, 2, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
-        else if (rem == 1) dec_round<LPR, 1, GRAD>(z, ldz, my_g, my_valid, base, i0, ns, n, lane, fl_ok, coef_pos, coef_neg, cstride, st);
-      }
-      if constexpr (GRAD) {
-        if constexpr (G > 1) {
-#pragma unroll
-          for (int o = 32; o >= LPR; o >>= 1) {
-            st.ga.x += __shfl_xor(st.ga.x, o, 64); st.ga.y += __shfl_xor(st.ga.y, o, 64);
-            st.ga.z += __shfl_xor(st.ga.z, o, 64); st.ga.w += __shfl_xor(st.ga.w, o, 64);
-            st.gb.x += __shfl_xor(st.gb.x, o, 64); st.gb.y += __shfl_xor(st.gb.y, o, 64);
-            st.gb.z += __shfl_xor(st.gb.z, o, 64); st.gb.w += __shfl_xor(st.gb.w, o, 64);
+      if (cur.p_hi - cur.p_lo <= DEC_CHUNK) {
+        dec_fwd_segment<LPR, GRAD>(z, ldz, zidx, col, cur.p_lo, cur.p_hi, cur.s_lo, cur.s_hi, cur.sr, cur.sc, true, cur.bc, cur.bg,
+                                   lane, fl_ok, coef_pos, coef_neg, cstride, st);
+      } else if constexpr (GRAD) {  // hub row: its pieces were computed by decoder_fused_fwd_long_kernel
+        const int c_lo = cur.p_lo / DEC_CHUNK, c_hi = (cur.p_hi - 1) / DEC_CHUNK;
+        if (lane < LPR && fl_ok) {
+          for (int cc = c_lo; cc <= c_hi; ++cc) {  // shares in ascending position order
+            const int slot = (cc == c_lo && cur.p_lo != cc * DEC_CHUNK) ? 1 : 0;
+            const float* o = gpart + ((size_t)cc * 2 + slot) * 2 * (4 * LPR) + 4 * fl;
+            const float4 t1 = *reinterpret_cast<const float4*>(o);
+            const float4 t2 = *reinterpret_cast<const float4*>(o + 4 * LPR);
+            st.ga.x += t1.x; st.ga.y += t1.y; st.ga.z += t1.z; st.ga.w += t1.w;
+            st.gb.x += t2.x; st.gb.y += t2.y; st.gb.z += t2.z; st.gb.w += t2.w;
           }
         }
+      }
+      if constexpr (GRAD) {
         if (lane < LPR && fl_ok) {
           *reinterpret_cast<float4*>(grow_pos + r * ldg + 4 * fl) = st.ga;
           *reinterpret_cast<float4*>(grow_neg + (int64_t)cur.sr * ldg + 4 * fl) = st.gb;
@@ -375,8 +461,6 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void decoder_fused_fwd_kernel(
 // once per pass and dz is written once.  Summation order and rounding are exactly those of the two-pass form over
 // spmm.hip (lane group g adds entries g, g+G, ... ascending, fixed butterfly, long rows cut at global positions
 // k*DEC_CHUNK with partials added in ascending order), so both forms give bitwise equal results.
-constexpr int DEC_CHUNK = 256;
-
 struct DecBwdArgs {
   const int32_t *t_rowptr, *t_col, *t_perm, *zidx;
   const float *coef_pos, *coef_neg, *z, *grow_pos, *grow_neg, *gscale;
@@ -471,15 +555,6 @@ __device__ __forceinline__ void dec_bwd_seg(const DecBwdArgs& a, int p_lo, int p
       s2.x += __shfl_xor(s2.x, o, 64); s2.y += __shfl_xor(s2.y, o, 64); s2.z += __shfl_xor(s2.z, o, 64); s2.w += __shfl_xor(s2.w, o, 64);
     }
   }
-}
-
-__device__ __forceinline__ int dec_row_of(const int32_t* __restrict__ rowptr, int64_t N, int p) {
-  int64_t lo = 0, hi = N;  // last r in [0,N) with rowptr[r] <= p
-  while (hi - lo > 1) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (rowptr[mid] <= p) lo = mid; else hi = mid;
-  }
-  return (int)lo;
 }
 
 // pieces of long rows: wave w handles global positions [w*DEC_CHUNK, (w+1)*DEC_CHUNK)
@@ -640,9 +715,11 @@ extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, 
 
 extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
   if (N <= 0 || nnz < 0 || D <= 0) return 0;
-  const size_t a = DEC_QUEUE_BYTES + ceeg_ws_part((size_t)(N / DEC_ROWS + 16) * 3, 4);
-  const size_t a0 = ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
   const size_t nchunk = (size_t)((nnz + DEC_CHUNK - 1) / DEC_CHUNK);
+  // forward: queue | loss partials (one slot per draw + two per chunk of hub rows) | hub-row shares of the row-side sums
+  const size_t a = DEC_QUEUE_BYTES + ceeg_ws_part(((size_t)(N / DEC_ROWS + 16) + 2 * (nchunk + 1)) * 3, 4) +
+                   ceeg_ws_part((nchunk + 1) * 2 * 2 * 4 * (size_t)dec_lpr(D), 4);
+  const size_t a0 = ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
   const size_t c0 = DEC_QUEUE_BYTES + ceeg_ws_part((nchunk + 1) * 2 * 2 * 4 * (size_t)dec_lpr(D), 4);  // fused backward: queue + long-row partials
   const size_t b = ceeg_spmm_ws_bytes(N, nnz, D);
   const size_t m = (a > b ? a : b) > a0 ? (a > b ? a : b) : a0;
@@ -652,7 +729,7 @@ extern "C" size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D) {
 extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                                       int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                                       float* coef_pos, float* coef_neg, int coef_stride, float* grow_pos, float* grow_neg, int64_t ldg,
-                                      float* sums, void* ws, size_t ws_bytes, void* stream) {
+                                      float* sums, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream) {
   if (coef_stride != 1 && coef_stride != 2) return CEEG_EINVAL;
   if ((grow_pos == nullptr) != (grow_neg == nullptr)) return CEEG_EINVAL;
   if (grow_pos && (ldg < D || (ldg % 4) != 0 || !ceeg_aligned(grow_pos, 16) || !ceeg_aligned(grow_neg, 16))) return CEEG_EINVAL;
@@ -665,20 +742,32 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   float* part = static_cast<float*>(ws);
   unsigned int* queue = static_cast<unsigned int*>(ws);  // queue counters, then one loss-partial slot per draw (unused slots stay 0)
   part = reinterpret_cast<float*>(static_cast<char*>(ws) + DEC_QUEUE_BYTES);
-  const int nslots = (int)(N / DEC_ROWS + 16);
+  const int64_t nchunk = (nnz + DEC_CHUNK - 1) / DEC_CHUNK;
+  const int64_t lslot0 = N / DEC_ROWS + 16;                       // first loss slot of the hub-row pieces
+  const int nslots = (int)(lslot0 + 2 * (nchunk + 1));
+  float* gpart = reinterpret_cast<float*>(static_cast<char*>(ws) + DEC_QUEUE_BYTES + ceeg_ws_part((size_t)nslots * 3, 4));
   if (hipMemsetAsync(ws, 0, DEC_QUEUE_BYTES + (size_t)nslots * 3 * 4, st) != hipSuccess) return CEEG_ELAUNCH;
   const int lpr = dec_lpr(D);
+  const bool has_long = nchunk > 0 && !(max_row_nnz >= 0 && max_row_nnz <= DEC_CHUNK);  // hint from the graph build skips the pass
+  const unsigned lblk = (unsigned)((nchunk + DEC_WAVES - 1) / DEC_WAVES);
   int64_t per_xcd = (N + 8 * DEC_WAVES * DEC_ROWS - 1) / (8 * DEC_WAVES * DEC_ROWS);  // enough blocks for one draw per wave ...
   if (per_xcd > DEC_BLOCKS_PER_XCD) per_xcd = DEC_BLOCKS_PER_XCD;                     // ... capped at a persistent grid
   const int nblk = (int)(8 * per_xcd);
 #define CEEG_DEC_CASE(L)                                                                                                              \
   case L:                                                                                                                             \
-    if (grow_pos)                                                                                                                     \
+    if (grow_pos) {                                                                                                                   \
+      if (has_long)                                                                                                                   \
+        hipLaunchKernelGGL((decoder_fused_fwd_long_kernel<L, true>), dim3(lblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, \
+                           sig_a, sig_b, sig_mod, coef_pos, coef_neg, coef_stride, gpart, part, lslot0);                                \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, true>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
-                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, part);                                                   \
-    else                                                                                                                              \
+                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, gpart, part);               \
+    } else {                                                                                                                          \
+      if (has_long)                                                                                                                   \
+        hipLaunchKernelGGL((decoder_fused_fwd_long_kernel<L, false>), dim3(lblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, \
+                           sig_a, sig_b, sig_mod, coef_pos, coef_neg, coef_stride, gpart, part, lslot0);                                \
       hipLaunchKernelGGL((decoder_fused_fwd_kernel<L, false>), dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, rowptr, col, N, D, sig_a, \
-                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, part);                                                   \
+                         sig_b, sig_mod, coef_pos, coef_neg, coef_stride, grow_pos, grow_neg, ldg, queue, gpart, part);               \
+    }                                                                                                                                 \
     break;
   switch (lpr) {
     CEEG_DEC_CASE(1)

@@ -431,7 +431,7 @@ class _FusedDecoder(torch.autograd.Function):
         with _lib.timed("decoder_fwd"):
             _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
                                                 cp.data_ptr(), cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
-                                                sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
+                                                sums.data_ptr(), p.max_row, ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
         ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
         ctx.save_for_backward(z, coef, inv)

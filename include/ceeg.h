@@ -175,12 +175,14 @@ int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32
  * grow_pos / grow_neg ([N, ldg] fp32, both or neither; NULL when no gradient is wanted): the row-side halves of
  * dz, accumulated while the gathered pieces are still in registers (unscaled):
  *   grow_pos[r] = sum_{p in row r} cp[p] z[col p],   grow_neg[sigma(r)] = sum_{p in row r} cn[p] z[col p].
- * Handing them to ceeg_decoder_fused_bwd leaves it two gather passes instead of four. */
+ * Handing them to ceeg_decoder_fused_bwd leaves it two gather passes instead of four.
+ * max_row_nnz: longest CSR row if the caller knows it (-1: unknown).  Rows longer than 256 entries (in-degree hubs) are
+ * cut at global positions k*256 and computed piecewise by a second kernel; a hint <= 256 skips that launch. */
 size_t ceeg_decoder_fused_ws_bytes(int64_t N, int64_t nnz, int D);
 int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* rowptr, const int32_t* col,
                            int64_t N, int64_t nnz, int D, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
                            float* coef_pos, float* coef_neg, int coef_stride, float* grow_pos, float* grow_neg, int64_t ldg,
-                           float* sums, void* ws, size_t ws_bytes, void* stream);
+                           float* sums, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream);
 /* Backward of the fused decoder: dz[n] = gp * (pos terms) + gn * (neg terms) where gp/gn are read from
  * the device (gscale[0], gscale[1]: upstream grad times 1/E_pos resp. 1/n_valid_neg).
  *   dz[n] = sum_{p in row n} gp*cp[p] z[col p]                 (n as dst of positives)

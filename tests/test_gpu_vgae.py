@@ -359,3 +359,41 @@ def test_global_attention_and_graph_layernorm_vs_oracle():
         (out2 * x.cuda()).sum().backward()
         _close(out2, ref2, rtol=1e-4, atol_rel=1e-5)
         _close(b2.grad, a2.grad, rtol=1e-3, atol_rel=1e-4)
+
+
+@pytest.mark.parametrize("D", [128, 32])
+def test_fused_decoder_indegree_hubs(D):
+    """Destination hubs (rows of 700, 300 and 5000 entries: split at global 256-entry positions and computed piecewise)
+    next to ordinary rows: loss, valid-negative count and gradient vs the oracle; both backward forms; reproducible."""
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    from oracle import ref_torch
+    N = 6000
+    rng = np.random.default_rng(D)
+    base = _graph(N, 20000, 77)
+    hubs = [np.stack([rng.choice(N - 1, k, replace=False) + (1 if h == 0 else 0), np.full(k, h)]) for h, k in ((0, 700), (4000, 300), (5999, 5000))]
+    hubs = [hb[:, hb[0] != hb[1]] for hb in hubs]
+    ei_np = np.concatenate([base] + hubs, axis=1)
+    ei_np = np.unique(ei_np, axis=1)
+    g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    assert g.dec.max_row > 256
+    a_, b_, ainv = sigma_params(N, 2, 4)
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, sig, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_)
+    z0 = torch.randn(N, D) * (1.5 / D ** 0.5)
+    a = z0.clone().requires_grad_(True)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
+    neg_ei = torch.from_numpy(np.stack([s, sig]).astype(np.int64))[:, torch.from_numpy(valid)]
+    ref = ref_torch.recon_loss(a, pos_ei, neg_ei)
+    ref.backward()
+    outs = []
+    for row_sums in (True, True, False):
+        b = z0.clone().cuda().requires_grad_(True)
+        rec, sums = _FusedDecoder.apply(b, g, a_, b_, ainv, row_sums)
+        rec.backward()
+        outs.append((rec.detach(), b.grad))
+        assert int(sums[2].item()) == int(valid.sum())
+        _close(rec, ref)
+        _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
