@@ -397,3 +397,32 @@ def test_fused_decoder_indegree_hubs(D):
         _close(rec, ref)
         _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_edge_cases_empty_and_single():
+    """Degenerate inputs the reference-style callers can produce: a graph without edges, a single node, one latent row."""
+    from causal_eeg_vae_amd import EventGraph, GATConv, GCNConv, VectorQuantizer, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    empty = torch.zeros(2, 0, dtype=torch.int64, device="cuda")
+    for N in (1, 5):
+        g = EventGraph(empty, N)
+        x = torch.randn(N, 8, device="cuda", requires_grad=True)
+        conv = GCNConv(8, 4).cuda()
+        out = conv(x, g)                                   # A_hat = I: out = x W^T + b
+        torch.testing.assert_close(out, x @ conv.lin.weight.t() + conv.bias, rtol=1e-5, atol=1e-6)
+        out.sum().backward()
+        gat = GATConv(8, 4).cuda()
+        o2 = gat(x, empty)                                 # only the self-loop: softmax weight 1
+        torch.testing.assert_close(o2, x @ gat.lin_src.weight.t() + gat.bias, rtol=1e-5, atol=1e-6)
+        z = torch.randn(N, 8, device="cuda", requires_grad=True)
+        a, b, ainv = sigma_params(N, 0, 0)
+        rec, sums = _FusedDecoder.apply(z, g, a, b, ainv)
+        rec.backward()
+        assert float(rec.detach()) == 0.0 and float(sums.abs().sum()) == 0.0 and float(z.grad.abs().sum()) == 0.0
+    vq = VectorQuantizer(16, 8, 0.25).cuda()
+    for B in (1, 3):
+        z = torch.randn(B, 8, device="cuda", requires_grad=True)
+        loss, zq, ppl, enc, idx = vq(z)
+        (loss + zq.sum()).backward()
+        assert tuple(idx.shape) == (B, 1) and tuple(enc.shape) == (B, 16) and torch.isfinite(loss) and torch.isfinite(z.grad).all()
+        assert torch.equal(zq.detach(), vq.embedding.weight[idx[:, 0]])
