@@ -664,6 +664,146 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void dec_bwd_rows_kernel(DecBwdArgs
   }
 }
 
+// Row kernel for D <= 128: every LANE GROUP (LPR lanes) owns its own row, so a wave has G = 64/LPR rows in flight instead
+// of one (the one-row form is latency-bound: ~2 GB of traffic in 1.5 ms).  A group walks its row LPR entries at a
+// time (metadata one entry per lane, broadcast inside the group), 4 dual gathers in flight, sums in entry order -
+// a different (still fixed) summation order than the one-row form, so equal to it only to rounding.
+template <int LPR>
+__global__ __launch_bounds__(DEC_WAVES * 64) void dec_bwd_rows_grouped_kernel(DecBwdArgs a) {
+  constexpr int G = 64 / LPR;
+  static_assert(G >= 2, "grouped form needs at least two rows per wave");
+  const int lane = threadIdx.x & 63;
+  const int gl = lane % LPR, grp = lane / LPR, gbase = lane - gl;
+  const bool fl_ok = 4 * gl < a.D;
+  const int xcd = blockIdx.x & 7;
+  const int64_t N = a.N;
+  const int64_t nnz = a.t_rowptr[N];
+  const int64_t r_begin = xcd == 0 ? 0 : dec_row_lower_bound(a.t_rowptr, N, nnz * xcd / 8);
+  const int64_t r_end = xcd == 7 ? N : dec_row_lower_bound(a.t_rowptr, N, nnz * (xcd + 1) / 8);
+  unsigned int* q = a.queue + xcd * 32;
+  const float gp = a.gscale[0], gn = a.gscale[1];
+  constexpr int DRAW = DEC_ROWS * G;  // rows per wave draw
+  unsigned int dv = 0;
+  if (lane == 0) dv = atomicAdd(q, (unsigned)DRAW);
+  for (;;) {
+    const int64_t base_r = r_begin + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
+    if (base_r >= r_end) break;
+    if (lane == 0) dv = atomicAdd(q, (unsigned)DRAW);
+    const int cnt = r_end - base_r < DRAW ? (int)(r_end - base_r) : DRAW;
+    for (int i0 = 0; i0 < cnt; i0 += 64) {   // row pointers 64 at a time (DRAW may exceed 63)
+      const int have = cnt - i0 < 64 ? cnt - i0 : 64;
+      int rlo = 0, rhi = 0;
+      if (lane < have) { rlo = a.t_rowptr[base_r + i0 + lane]; rhi = a.t_rowptr[base_r + i0 + lane + 1]; }
+      // bounds of this group's row in iteration i (empty past the batch); exchanges by ALL lanes: a masked-off source reads 0
+      auto bounds = [&](int i, int& lo, int& hi) {
+        const int ri = i + grp;
+        lo = __shfl(rlo, ri & 63, 64);
+        const int h = __shfl(rhi, ri & 63, 64);
+        hi = (i < have && ri < have) ? h : lo;
+      };
+      // first LPR entries of a (short) row: raw = (tcol, tperm); resolved = gather rows + coefficient pair
+      auto raw = [&](int lo, int hi, int& rc, int& rp) {
+        rc = 0; rp = 0;
+        if (hi - lo <= DEC_CHUNK && lo + gl < hi) { rc = a.t_col[lo + gl]; rp = a.t_perm[lo + gl]; }
+      };
+      auto resolve = [&](int lo, int hi, int rc, int rp, int& g1, int& g2, float& c1, float& c2) {
+        g1 = 0; g2 = 0; c1 = 0.f; c2 = 0.f;
+        if (hi - lo <= DEC_CHUNK && lo + gl < hi) {
+          const int s = (int)ceeg_block_affine((int64_t)rc, a.sig_a, a.sig_b, a.sig_mod);
+          g1 = a.zidx ? a.zidx[rc] : rc;
+          g2 = a.zidx ? a.zidx[s] : s;
+          c1 = a.coef_pos[(int64_t)rp * a.cstride];
+          c2 = a.coef_neg[(int64_t)rp * a.cstride];
+        }
+      };
+      // pipeline: iteration i gathers; the resolve loads of i+G and the raw loads of i+2G are issued first (one wait covers all)
+      int lo0, hi0, lo1, hi1, lo2, hi2;
+      bounds(0, lo0, hi0);
+      bounds(G, lo1, hi1);
+      int rc0, rp0, rc1, rp1;
+      raw(lo0, hi0, rc0, rp0);
+      raw(lo1, hi1, rc1, rp1);
+      int g1, g2;
+      float c1, c2;
+      resolve(lo0, hi0, rc0, rp0, g1, g2, c1, c2);
+      for (int i = 0; i < have; i += G) {
+        int g1n, g2n;
+        float c1n, c2n;
+        resolve(lo1, hi1, rc1, rp1, g1n, g2n, c1n, c2n);
+        bounds(i + 2 * G, lo2, hi2);
+        int rc2, rp2;
+        raw(lo2, hi2, rc2, rp2);
+        const int p_lo = lo0, p_hi = hi0;
+        const bool live = i + grp < have;
+        const int64_t r = base_r + i0 + i + grp;
+        float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+        if (p_hi - p_lo <= DEC_CHUNK) {
+          for (int base = p_lo; __any(base < p_hi); base += LPR) {
+            const int n = p_hi - base < LPR ? (p_hi - base > 0 ? p_hi - base : 0) : LPR;
+            if (base != p_lo) {   // rows longer than LPR entries: later batches are fetched in line (wave-uniform branch per lane group)
+              int rc, rp;
+              raw(base, p_hi, rc, rp);
+              resolve(base, p_hi, rc, rp, g1, g2, c1, c2);
+            }
+            for (int j0 = 0; __any(j0 < n); j0 += 4) {
+              float4 x1[4], x2[4];
+              float v1[4], v2[4];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int src = gbase + ((j0 + k) & (LPR - 1));
+                const int e1 = __shfl(g1, src, 64), e2 = __shfl(g2, src, 64);
+                v1[k] = __shfl(c1, src, 64);
+                v2[k] = __shfl(c2, src, 64);
+                x1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                x2[k] = x1[k];
+                if (j0 + k < n && fl_ok) {
+                  x1[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)e1 * a.ldz + 4 * gl);
+                  x2[k] = *reinterpret_cast<const float4*>(a.z + (int64_t)e2 * a.ldz + 4 * gl);
+                }
+              }
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                if (j0 + k < n) {
+                  s1.x = __fmaf_rn(v1[k], x1[k].x, s1.x); s1.y = __fmaf_rn(v1[k], x1[k].y, s1.y);
+                  s1.z = __fmaf_rn(v1[k], x1[k].z, s1.z); s1.w = __fmaf_rn(v1[k], x1[k].w, s1.w);
+                  s2.x = __fmaf_rn(v2[k], x2[k].x, s2.x); s2.y = __fmaf_rn(v2[k], x2[k].y, s2.y);
+                  s2.z = __fmaf_rn(v2[k], x2[k].z, s2.z); s2.w = __fmaf_rn(v2[k], x2[k].w, s2.w);
+                }
+              }
+            }
+          }
+        } else if (fl_ok) {  // hub row: pieces from dec_bwd_long_kernel<LPR>, ascending
+          const int c_lo = p_lo / DEC_CHUNK, c_hi = (p_hi - 1) / DEC_CHUNK;
+          for (int c = c_lo; c <= c_hi; ++c) {
+            const int slot = (c == c_lo && p_lo != c * DEC_CHUNK) ? 1 : 0;
+            const float* o = a.partial + ((size_t)c * 2 + slot) * 2 * (4 * LPR) + 4 * gl;
+            const float4 t1 = *reinterpret_cast<const float4*>(o);
+            const float4 t2 = *reinterpret_cast<const float4*>(o + 4 * LPR);
+            s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+            s2.x += t2.x; s2.y += t2.y; s2.z += t2.z; s2.w += t2.w;
+          }
+        }
+        if (live && fl_ok) {
+          if (a.grow_pos) {
+            const float4 A = *reinterpret_cast<const float4*>(a.grow_pos + r * a.ldg + 4 * gl);
+            const float4 B = *reinterpret_cast<const float4*>(a.grow_neg + r * a.ldg + 4 * gl);
+            s1.x += A.x; s1.y += A.y; s1.z += A.z; s1.w += A.w;
+            s2.x += B.x; s2.y += B.y; s2.z += B.z; s2.w += B.w;
+          }
+          s1.x *= gp; s1.y *= gp; s1.z *= gp; s1.w *= gp;
+          s2.x *= gn; s2.y *= gn; s2.z *= gn; s2.w *= gn;
+          float4 o;
+          o.x = s2.x + s1.x; o.y = s2.y + s1.y; o.z = s2.z + s1.z; o.w = s2.w + s1.w;
+          *reinterpret_cast<float4*>(a.dz + r * a.lddz + 4 * gl) = o;
+        }
+        lo0 = lo1; hi0 = hi1; lo1 = lo2; hi1 = hi2;
+        g1 = g1n; g2 = g2n; c1 = c1n; c2 = c2n;
+        rc1 = rc2; rp1 = rp2;
+      }
+    }
+  }
+}
+
 int dec_lpr(int D) {
   const int need = (D + 3) / 4;
   int l = 1;
@@ -746,10 +886,11 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   const int64_t lslot0 = N / DEC_ROWS + 16;                       // first loss slot of the hub-row pieces
   const int nslots = (int)(lslot0 + 2 * (nchunk + 1));
   float* gpart = reinterpret_cast<float*>(static_cast<char*>(ws) + DEC_QUEUE_BYTES + ceeg_ws_part((size_t)nslots * 3, 4));
-  if (hipMemsetAsync(ws, 0, DEC_QUEUE_BYTES + (size_t)nslots * 3 * 4, st) != hipSuccess) return CEEG_ELAUNCH;
   const int lpr = dec_lpr(D);
   const bool has_long = nchunk > 0 && !(max_row_nnz >= 0 && max_row_nnz <= DEC_CHUNK);  // hint from the graph build skips the pass
   const unsigned lblk = (unsigned)((nchunk + DEC_WAVES - 1) / DEC_WAVES);
+  const int nsum = has_long ? nslots : (int)lslot0;               // slots that can hold anything
+  if (hipMemsetAsync(ws, 0, DEC_QUEUE_BYTES + (size_t)nsum * 3 * 4, st) != hipSuccess) return CEEG_ELAUNCH;
   int64_t per_xcd = (N + 8 * DEC_WAVES * DEC_ROWS - 1) / (8 * DEC_WAVES * DEC_ROWS);  // enough blocks for one draw per wave ...
   if (per_xcd > DEC_BLOCKS_PER_XCD) per_xcd = DEC_BLOCKS_PER_XCD;                     // ... capped at a persistent grid
   const int nblk = (int)(8 * per_xcd);
@@ -781,7 +922,7 @@ extern "C" int ceeg_decoder_fused_fwd(const float* z, int64_t ldz, const int32_t
   }
 #undef CEEG_DEC_CASE
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nslots, 3, sums);
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nsum, 3, sums);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
@@ -831,11 +972,18 @@ extern "C" int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t
     const bool has_long = nchunk > 0 && !(max_trow_nnz >= 0 && max_trow_nnz <= DEC_CHUNK);
     int64_t per_xcd = (N + 8 * DEC_WAVES * DEC_ROWS - 1) / (8 * DEC_WAVES * DEC_ROWS);
     if (per_xcd > DEC_BLOCKS_PER_XCD) per_xcd = DEC_BLOCKS_PER_XCD;
+    const char* genv = getenv("CEEG_DEC_BWD_GROUPED");
+    const bool grouped = !(genv && genv[0] == '0');
 #define CEEG_DECB_CASE(L)                                                                                                         \
   case L:                                                                                                                         \
     if (has_long)                                                                                                                 \
       hipLaunchKernelGGL(dec_bwd_long_kernel<L>, dim3((unsigned)((nchunk + DEC_WAVES - 1) / DEC_WAVES)), dim3(DEC_WAVES * 64), 0, st, a); \
-    hipLaunchKernelGGL(dec_bwd_rows_kernel<L>, dim3((unsigned)(8 * per_xcd)), dim3(DEC_WAVES * 64), 0, st, a);                     \
+    if constexpr (L <= 32) {                                                                                                      \
+      if (grouped) hipLaunchKernelGGL(dec_bwd_rows_grouped_kernel<L>, dim3((unsigned)(8 * per_xcd)), dim3(DEC_WAVES * 64), 0, st, a); \
+      else hipLaunchKernelGGL(dec_bwd_rows_kernel<L>, dim3((unsigned)(8 * per_xcd)), dim3(DEC_WAVES * 64), 0, st, a);               \
+    } else {                                                                                                                      \
+      hipLaunchKernelGGL(dec_bwd_rows_kernel<L>, dim3((unsigned)(8 * per_xcd)), dim3(DEC_WAVES * 64), 0, st, a);                   \
+    }                                                                                                                             \
     break;
     switch (lpr) {
       CEEG_DECB_CASE(1)

@@ -242,14 +242,19 @@ def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e):
     # the fused two-sum backward kernel == the same sums run as two SpMM passes, bit for bit (hub rows included)
     import os
     grads = []
-    for env in ("0", "1"):
-        os.environ["CEEG_DEC_BWD_TWO_PASS"] = env
-        x3 = zq.clone().requires_grad_(True)
-        r3, _ = _FusedDecoder.apply(x3, g, a_, b_, ainv, True, None, W, idx)
-        (r3 * 0.7).backward()
-        grads.append(x3.grad.clone())
-    os.environ.pop("CEEG_DEC_BWD_TWO_PASS")
+    try:
+        os.environ["CEEG_DEC_BWD_GROUPED"] = "0"   # the one-row-per-wave form shares the SpMM's summation order
+        for env in ("0", "1"):
+            os.environ["CEEG_DEC_BWD_TWO_PASS"] = env
+            x3 = zq.clone().requires_grad_(True)
+            r3, _ = _FusedDecoder.apply(x3, g, a_, b_, ainv, True, None, W, idx)
+            (r3 * 0.7).backward()
+            grads.append(x3.grad.clone())
+    finally:
+        os.environ.pop("CEEG_DEC_BWD_TWO_PASS", None)
+        os.environ.pop("CEEG_DEC_BWD_GROUPED", None)
     assert torch.equal(grads[0], grads[1])
+    _close(x2.grad, grads[0], rtol=1e-4, atol_rel=1e-6)   # default (row per lane group) form: same sums, other order
 
 
 def test_config1_plumbing_csv_to_training(tmp_path):
