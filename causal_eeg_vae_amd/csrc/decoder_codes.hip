@@ -1,0 +1,505 @@
+// Fused decoder for a QUANTISED latent (z[n] = W[code[n]], W the VQ codebook) on gfx950 (MI355X).
+//
+// Same arithmetic contract as decoder.hip (upstream PyG InnerProductDecoder + GAE.recon_loss, literal "+EPS" form,
+// permutation-structured negatives), but built on what quantisation gives for free:
+//   * every dot product <z_i, z_j> is an entry of the Gram matrix  G = W W^T  (K x K floats, 1 MB at K = 512, L2-resident):
+//     the forward reads TWO FLOATS per (entry, kind) instead of gathering a D*4-byte row through L2;
+//   * every gradient term is (coefficient) x (codebook row): the backward keeps a 64-column slab of the WHOLE codebook in
+//     LDS (K x 64 floats = 128 KB of the CU's 160 KB) and reads its rows with ds_read_b128 - no global gathers of
+//     latent rows at all.  D/64 slabs are swept by different workgroups.
+// The L2 -> CU gather plateau (~12 TB/s) that bounded decoder.hip's 512-byte row gathers is gone: what
+// is left are the index/coefficient streams (16 bytes per entry) and LDS reads.
+//
+// Forward  : dc_gram_kernel -> dc_coef_rows_kernel (+ dc_coef_long_kernel for rows > DC_CHUNK) -> dc_finalize_kernel
+//            leaves rec[p] = (cp, cn, code[r] | code[sigma r] << 16, code[col p]) for CSR entry p of row r.
+// Backward : dc_grad_rows_kernel (+ dc_grad_long_kernel per direction when it has lists > DC_CHUNK):
+//   dz[n] = gp * ( sum_{p in row n} cp[p] W[kc p]  +  sum_{q in trow n} cp[tperm q] W[kr(tperm q)] )
+//         + gn * ( sum_{p in row sigma^-1 n} cn[p] W[kc p]  +  sum_{q in trow n} cn[tperm q] W[ksr(tperm q)] )
+// One 16-lane group (a DPP row) owns a row / node: entries are held one per lane and broadcast inside the group with
+// row_newbcast (no LDS traffic for the shuffles), four rows per wave in flight.  No float atomics; every sum has a
+// fixed order (entry order inside a list, lists in the order above, long lists in ascending 256-entry pieces).
+#include "ceeg_internal.h"
+
+namespace {
+
+constexpr float DC_EPS = 1e-15f;
+constexpr int DC_CHUNK = 256;          // lists longer than this are cut at the GLOBAL positions k*DC_CHUNK
+constexpr int DC_CW = 64;              // codebook columns per LDS slab: 16 lanes x float4
+constexpr int DC_MAX_K = 576;          // K * DC_CW * 4 bytes <= 144 KiB of LDS
+constexpr int DC_GRAD_THREADS = 1024;  // one workgroup per CU (the slab fills its LDS), 16 waves
+constexpr int DC_MAX_GRAD_BLOCKS = 256;
+
+struct DcGradArgs {
+  const float* W;
+  int64_t ldw;
+  int K, D;
+  const int32_t *rowptr, *t_rowptr, *t_perm;
+  const uint4* rec;
+  const float* gscale;
+  float* dz;
+  int64_t lddz, N, nnz;
+  int64_t sig_b, sig_ainv, sig_mod;
+  unsigned int* queue;
+  float* part_csr;   // [chunk*2+slot][2][D]: pieces of long CSR rows       (sum 0: cp W[kc], sum 1: cn W[kc])
+  float* part_t;     // [chunk*2+slot][2][D]: pieces of long transposed rows (sum 0: cp W[kr], sum 1: cn W[ksr])
+};
+
+template <int T>
+__device__ __forceinline__ int dc_bcast(int v) {  // lane T of the caller's 16-lane DPP row, in every lane of that row
+  return __builtin_amdgcn_update_dpp(0, v, 0x150 + T, 0xf, 0xf, false);
+}
+template <int T>
+__device__ __forceinline__ float dc_bcastf(float v) { return __int_as_float(dc_bcast<T>(__float_as_int(v))); }
+
+#define DC_FOR16(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15)
+
+__device__ __forceinline__ int dc_clamp_code(int k, int K) { return k < 0 ? 0 : (k >= K ? K - 1 : k); }
+
+__device__ __forceinline__ int64_t dc_sigma_inv(int64_t y, int64_t ainv, int64_t b, int64_t mod) {
+  const uint64_t l = (uint64_t)y % (uint64_t)mod;
+  const uint64_t t = (l + (uint64_t)mod - (uint64_t)b) % (uint64_t)mod;
+  return y - (int64_t)l + (int64_t)(((uint64_t)ainv * t) % (uint64_t)mod);
+}
+
+__device__ __forceinline__ bool dc_sorted_has(const int32_t* __restrict__ col, int lo, int end, int32_t s) {
+  int hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  return lo < end && col[lo] == s;
+}
+
+// literal "+EPS" terms and their derivatives (as decoder.hip: dec_pos / dec_neg)
+__device__ __forceinline__ void dc_terms(float vp, float vn, float& tp, float& cp, float& tn, float& cn) {
+  const float sp = 1.0f / (1.0f + expf(-vp));
+  tp = -logf(sp + DC_EPS);
+  cp = -(sp * (1.0f - sp)) / (sp + DC_EPS);
+  const float sn = 1.0f / (1.0f + expf(-vn));
+  const float om = 1.0f - sn;
+  tn = -logf(om + DC_EPS);
+  cn = (sn * om) / (om + DC_EPS);
+}
+
+// ------------------------------------------------------------------------------------------------ Gram matrix
+// G[a][b] = k-ascending fmaf chain from 0 of W[a][k] * W[b][k]  (fmaf(x, y, acc) is symmetric in x, y: G is exactly symmetric)
+__global__ __launch_bounds__(256) void dc_gram_kernel(const float* __restrict__ W, int64_t ldw, int K, int D, float* __restrict__ G) {
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  const int a = blockIdx.y;
+  if (b >= K) return;
+  const float* wa = W + (int64_t)a * ldw;
+  const float* wb = W + (int64_t)b * ldw;
+  float acc = 0.f;
+  for (int k = 0; k < D; k += 4) {
+    const float4 x = *reinterpret_cast<const float4*>(wa + k);
+    const float4 y = *reinterpret_cast<const float4*>(wb + k);
+    acc = __fmaf_rn(x.x, y.x, acc);
+    acc = __fmaf_rn(x.y, y.y, acc);
+    acc = __fmaf_rn(x.z, y.z, acc);
+    acc = __fmaf_rn(x.w, y.w, acc);
+  }
+  G[(size_t)a * K + b] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ forward: coefficients
+// Wave w owns rows [64 w, 64 w + 64): the row pointers, sigma-rows and codes of all 64 arrive in one lane-parallel
+// load; group g walks rows 4 it + g, 16 entries at a time.  Static assignment: the loss partial of wave w goes to slot w,
+// so the sums do not depend on scheduling.
+__global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
+                                                           int64_t sig_a, int64_t sig_b, int64_t sig_mod, uint4* __restrict__ rec,
+                                                           float* __restrict__ part) {
+  const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t row0 = w * 64;
+  if (row0 >= N) return;
+  const int64_t r = row0 + lane;
+  int lo = 0, hi = 0, sr = 0, slo = 0, shi = 0, kr = 0, ksr = 0;
+  if (r < N) {
+    lo = rowptr[r];
+    hi = rowptr[r + 1];
+    sr = (int)ceeg_block_affine(r, sig_a, sig_b, sig_mod);
+    slo = rowptr[sr];
+    shi = rowptr[sr + 1];
+    kr = dc_clamp_code(code[r], K);
+    ksr = dc_clamp_code(code[sr], K);
+    if (hi - lo > DC_CHUNK) hi = lo;  // hub row: dc_coef_long_kernel
+  }
+  const int cnt = N - row0 < 64 ? (int)(N - row0) : 64;
+  float a_pos = 0.f, a_neg = 0.f, a_cnt = 0.f;
+  for (int it = 0; it * 4 < cnt; ++it) {
+    const int j = it * 4 + grp;
+    const int p_lo = __shfl(lo, j, 64), p_hi = __shfl(hi, j, 64);
+    const int g_sr = __shfl(sr, j, 64), g_slo = __shfl(slo, j, 64), g_shi = __shfl(shi, j, 64);
+    const int g_kr = __shfl(kr, j, 64), g_ksr = __shfl(ksr, j, 64);
+    const int s_n = g_shi - g_slo;
+    const bool s_short = s_n <= 16;
+    int sc = -1;  // sigma-row's columns across the group's lanes (never equal to a column id when absent)
+    if (p_lo < p_hi && s_short && gl < s_n) sc = col[g_slo + gl];
+    const float* gr = G + (size_t)g_kr * K;
+    const float* gs = G + (size_t)g_ksr * K;
+    for (int base = p_lo; __any(base < p_hi); base += 16) {
+      const int p = base + gl;
+      const bool live = p < p_hi;
+      int c = 0, kc = 0;
+      if (live) {
+        c = col[p];
+        kc = dc_clamp_code(code[c], K);
+      }
+      bool hit = false;
+#define DC_HIT(T) hit |= (c == dc_bcast<T>(sc));
+      DC_FOR16(DC_HIT)
+#undef DC_HIT
+      if (live && !s_short) hit = dc_sorted_has(col, g_slo, g_shi, c);
+      if (live) {
+        float tp, cp, tn, cn;
+        dc_terms(gr[kc], gs[kc], tp, cp, tn, cn);
+        const bool valid = c != g_sr && !hit;
+        if (!valid) { tn = 0.f; cn = 0.f; }
+        rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)g_kr | ((unsigned)g_ksr << 16), (unsigned)kc);
+        a_pos += tp;
+        a_neg += tn;
+        a_cnt += valid ? 1.0f : 0.f;
+      }
+    }
+  }
+  const float t0 = ceeg_wave_sum(a_pos), t1 = ceeg_wave_sum(a_neg), t2 = ceeg_wave_sum(a_cnt);
+  if (lane == 0) {
+    float* o = part + (size_t)w * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+
+// pieces of hub rows: one wave per item (lo, hi, chunk*2+slot, row), 64 entries at a time; loss partial -> slot0 + item
+__global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+                                                           const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                           const int4* __restrict__ items, int64_t n_items, int64_t sig_a, int64_t sig_b,
+                                                           int64_t sig_mod, uint4* __restrict__ rec, float* __restrict__ part, int64_t slot0) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_items) return;
+  const int4 itv = items[i];
+  const int lo = itv.x, hi = itv.y, r = itv.w;
+  const int sr = (int)ceeg_block_affine((int64_t)r, sig_a, sig_b, sig_mod);
+  const int slo = rowptr[sr], shi = rowptr[sr + 1];
+  const int kr = dc_clamp_code(code[r], K), ksr = dc_clamp_code(code[sr], K);
+  const float* gr = G + (size_t)kr * K;
+  const float* gs = G + (size_t)ksr * K;
+  float a_pos = 0.f, a_neg = 0.f, a_cnt = 0.f;
+  for (int base = lo; base < hi; base += 64) {
+    const int p = base + lane;
+    if (p < hi) {
+      const int c = col[p];
+      const int kc = dc_clamp_code(code[c], K);
+      float tp, cp, tn, cn;
+      dc_terms(gr[kc], gs[kc], tp, cp, tn, cn);
+      const bool valid = c != sr && !dc_sorted_has(col, slo, shi, c);
+      if (!valid) { tn = 0.f; cn = 0.f; }
+      rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)kr | ((unsigned)ksr << 16), (unsigned)kc);
+      a_pos += tp;
+      a_neg += tn;
+      a_cnt += valid ? 1.0f : 0.f;
+    }
+  }
+  const float t0 = ceeg_wave_sum(a_pos), t1 = ceeg_wave_sum(a_neg), t2 = ceeg_wave_sum(a_cnt);
+  if (lane == 0) {
+    float* o = part + (size_t)(slot0 + i) * 3;
+    o[0] = t0; o[1] = t1; o[2] = t2;
+  }
+}
+
+__global__ __launch_bounds__(1024) void dc_finalize_kernel(const float* __restrict__ part, int64_t nslot, float* __restrict__ out) {
+  __shared__ double red[3][1024];
+  double s[3] = {0.0, 0.0, 0.0};
+  for (int64_t i = threadIdx.x; i < nslot; i += 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] += (double)part[(size_t)i * 3 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) red[k][threadIdx.x] = s[k];
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out[threadIdx.x] = (float)red[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------------ backward: gradient
+__device__ __forceinline__ void dc_fma4(float c, const float4& x, float4& s) {
+  s.x = __fmaf_rn(c, x.x, s.x);
+  s.y = __fmaf_rn(c, x.y, s.y);
+  s.z = __fmaf_rn(c, x.z, s.z);
+  s.w = __fmaf_rn(c, x.w, s.w);
+}
+
+// one batch: the group's lanes hold (cf, k) of up to 16 entries (n live; the others carry cf = 0, k = 0): s += sum_t cf_t W[k_t]
+__device__ __forceinline__ void dc_batch1(const float4* lds4, int gl, float cf, int k, int n, float4& s) {
+  do {
+#define DC_STEP(T)                              \
+    if (!__any(n > T)) break;                   \
+    {                                           \
+      const float ct = dc_bcastf<T>(cf);        \
+      const int kt = dc_bcast<T>(k);            \
+      dc_fma4(ct, lds4[kt * 16 + gl], s);       \
+    }
+    DC_FOR16(DC_STEP)
+#undef DC_STEP
+  } while (0);
+}
+// the same with two (coefficient, code) pairs per entry and two sums
+__device__ __forceinline__ void dc_batch2(const float4* lds4, int gl, float ca, int ka, float cb, int kb, int n, float4& sa, float4& sb) {
+  do {
+#define DC_STEP(T)                                        \
+    if (!__any(n > T)) break;                             \
+    {                                                     \
+      const float at = dc_bcastf<T>(ca);                  \
+      const int kat = dc_bcast<T>(ka);                    \
+      const float bt = dc_bcastf<T>(cb);                  \
+      const int kbt = dc_bcast<T>(kb);                    \
+      dc_fma4(at, lds4[kat * 16 + gl], sa);               \
+      dc_fma4(bt, lds4[kbt * 16 + gl], sb);               \
+    }
+    DC_FOR16(DC_STEP)
+#undef DC_STEP
+  } while (0);
+}
+
+__device__ __forceinline__ void dc_fill_slab(const DcGradArgs& a, int slab, float4* lds4) {
+  for (int i = threadIdx.x; i < a.K * 16; i += DC_GRAD_THREADS)
+    lds4[i] = *reinterpret_cast<const float4*>(a.W + (int64_t)(i >> 4) * a.ldw + slab * DC_CW + 4 * (i & 15));
+  __syncthreads();
+}
+
+__device__ __forceinline__ void dc_add_pieces(const float* __restrict__ part, int lo, int hi, int sum, int D, int col0, float4& s) {
+  const int c_lo = lo / DC_CHUNK, c_hi = (hi - 1) / DC_CHUNK;
+  for (int c = c_lo; c <= c_hi; ++c) {  // ascending position order
+    const int slot = (c == c_lo && lo != c * DC_CHUNK) ? 1 : 0;
+    const float4 t = *reinterpret_cast<const float4*>(part + (((size_t)c * 2 + slot) * 2 + sum) * D + col0);
+    s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+  }
+}
+
+// Persistent grid, one workgroup per CU; workgroup b sweeps slab b % nslab.  Every wave draws 64 consecutive nodes from its
+// slab's counter (integer atomics only: which wave computes a node does not change the node's result).
+__global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* lds4 = reinterpret_cast<float4*>(smem);
+  const int nslab = a.D / DC_CW;
+  const int slab = blockIdx.x % nslab;
+  dc_fill_slab(a, slab, lds4);
+  const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+  const int col0 = slab * DC_CW + 4 * gl;
+  const float gp = a.gscale[0], gn = a.gscale[1];
+  unsigned int* q = a.queue + slab * 32;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  for (;;) {
+    unsigned int dv = 0;
+    if (lane == 0) dv = atomicAdd(q, 64u);
+    const int64_t base_n = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
+    if (base_n >= a.N) break;
+    const int64_t n = base_n + lane;
+    int alo = 0, ahi = 0, blo = 0, bhi = 0, clo = 0, chi = 0;
+    if (n < a.N) {
+      alo = a.rowptr[n];
+      ahi = a.rowptr[n + 1];
+      const int64_t m = dc_sigma_inv(n, a.sig_ainv, a.sig_b, a.sig_mod);
+      blo = a.rowptr[m];
+      bhi = a.rowptr[m + 1];
+      clo = a.t_rowptr[n];
+      chi = a.t_rowptr[n + 1];
+    }
+    const int cnt = a.N - base_n < 64 ? (int)(a.N - base_n) : 64;
+    for (int it = 0; it * 4 < cnt; ++it) {
+      const int j = it * 4 + grp;
+      const int A_lo = __shfl(alo, j, 64), A_hi = __shfl(ahi, j, 64);
+      const int B_lo = __shfl(blo, j, 64), B_hi = __shfl(bhi, j, 64);
+      const int C_lo = __shfl(clo, j, 64), C_hi = __shfl(chi, j, 64);
+      const bool a_long = A_hi - A_lo > DC_CHUNK, b_long = B_hi - B_lo > DC_CHUNK, c_long = C_hi - C_lo > DC_CHUNK;
+      const int a_hi = a_long ? A_lo : A_hi, b_hi = b_long ? B_lo : B_hi, c_hi = c_long ? C_lo : C_hi;
+      // first batches of the three lists: the dependent chain (t_perm -> rec) first, then the two streamed ones
+      int tp = 0;
+      if (C_lo + gl < c_hi) tp = a.t_perm[C_lo + gl];
+      uint4 ra = zero4, rb = zero4, rc = zero4;
+      if (A_lo + gl < a_hi) ra = a.rec[A_lo + gl];
+      if (B_lo + gl < b_hi) rb = a.rec[B_lo + gl];
+      if (C_lo + gl < c_hi) rc = a.rec[tp];
+      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1, s4 = s1;
+      // (1) n as destination of positives: sum_{p in row n} cp W[kc]
+      for (int base = A_lo; __any(base < a_hi); base += 16) {
+        if (base != A_lo) { ra = zero4; if (base + gl < a_hi) ra = a.rec[base + gl]; }
+        const int nb = a_hi - base;
+        dc_batch1(lds4, gl, __uint_as_float(ra.x), (int)ra.w, nb < 0 ? 0 : nb, s1);
+      }
+      // (3) n as negative endpoint sigma(m): sum_{p in row m} cn W[kc]
+      for (int base = B_lo; __any(base < b_hi); base += 16) {
+        if (base != B_lo) { rb = zero4; if (base + gl < b_hi) rb = a.rec[base + gl]; }
+        const int nb = b_hi - base;
+        dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3);
+      }
+      // (2) + (4) n as source: sum_q cp W[kr], sum_q cn W[ksr] over the transposed row
+      for (int base = C_lo; __any(base < c_hi); base += 16) {
+        if (base != C_lo) {
+          rc = zero4;
+          if (base + gl < c_hi) rc = a.rec[a.t_perm[base + gl]];
+        }
+        const int nb = c_hi - base;
+        dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2, s4);
+      }
+      if (a_long) dc_add_pieces(a.part_csr, A_lo, A_hi, 0, a.D, col0, s1);
+      if (b_long) dc_add_pieces(a.part_csr, B_lo, B_hi, 1, a.D, col0, s3);
+      if (c_long) {
+        dc_add_pieces(a.part_t, C_lo, C_hi, 0, a.D, col0, s2);
+        dc_add_pieces(a.part_t, C_lo, C_hi, 1, a.D, col0, s4);
+      }
+      if (j < cnt) {
+        float4 o;
+        o.x = gn * (s3.x + s4.x) + gp * (s1.x + s2.x);
+        o.y = gn * (s3.y + s4.y) + gp * (s1.y + s2.y);
+        o.z = gn * (s3.z + s4.z) + gp * (s1.z + s2.z);
+        o.w = gn * (s3.w + s4.w) + gp * (s1.w + s2.w);
+        *reinterpret_cast<float4*>(a.dz + (base_n + j) * a.lddz + col0) = o;
+      }
+    }
+  }
+}
+
+// pieces of long lists: one 16-lane group per item (lo, hi, chunk*2+slot, row); TRANSPOSED: positions index t_perm
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_long_kernel(DcGradArgs a, const int4* __restrict__ items, int64_t n_items) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* lds4 = reinterpret_cast<float4*>(smem);
+  const int nslab = a.D / DC_CW;
+  const int slab = blockIdx.x % nslab;
+  dc_fill_slab(a, slab, lds4);
+  const int gl = threadIdx.x & 15;
+  const int col0 = slab * DC_CW + 4 * gl;
+  const int64_t stride = (int64_t)(gridDim.x / nslab) * (DC_GRAD_THREADS / 16);
+  float* part = TRANSPOSED ? a.part_t : a.part_csr;
+  for (int64_t i = (int64_t)(blockIdx.x / nslab) * (DC_GRAD_THREADS / 16) + (threadIdx.x >> 4); __any(i < n_items); i += stride) {
+    int lo = 0, hi = 0, slot = 0;
+    if (i < n_items) {
+      const int4 itv = items[i];
+      lo = itv.x; hi = itv.y; slot = itv.z;
+    }
+    float4 sa = make_float4(0.f, 0.f, 0.f, 0.f), sb = sa;
+    for (int base = lo; __any(base < hi); base += 16) {
+      uint4 r = make_uint4(0u, 0u, 0u, 0u);
+      if (base + gl < hi) r = a.rec[TRANSPOSED ? a.t_perm[base + gl] : base + gl];
+      const int ka = TRANSPOSED ? (int)(r.z & 0xffffu) : (int)r.w;
+      const int kb = TRANSPOSED ? (int)(r.z >> 16) : (int)r.w;
+      const int nb = hi - base;
+      dc_batch2(lds4, gl, __uint_as_float(r.x), ka, __uint_as_float(r.y), kb, nb < 0 ? 0 : nb, sa, sb);
+    }
+    if (hi > lo) {
+      float* o = part + ((size_t)slot * 2) * a.D + col0;
+      *reinterpret_cast<float4*>(o) = sa;
+      *reinterpret_cast<float4*>(o + a.D) = sb;
+    }
+  }
+}
+
+bool dc_supported(int n_e, int D) { return n_e >= 1 && n_e <= DC_MAX_K && D >= DC_CW && D <= 256 && (D % DC_CW) == 0; }
+size_t dc_part_bytes(int64_t nnz, int D, int64_t n_items) {
+  if (n_items <= 0) return 0;
+  const size_t nchunk = (size_t)((nnz + DC_CHUNK - 1) / DC_CHUNK);
+  return ceeg_ws_part((nchunk + 1) * 2 * 2 * (size_t)D, 4);
+}
+
+}  // namespace
+
+extern "C" int ceeg_decoder_codes_chunk(void) { return DC_CHUNK; }
+extern "C" int ceeg_decoder_codes_supported(int n_e, int D) { return dc_supported(n_e, D) ? 1 : 0; }
+
+extern "C" size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong) {
+  if (N <= 0 || nnz < 0 || !dc_supported(n_e, D) || n_long < 0 || n_tlong < 0) return 0;
+  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part(((size_t)((N + 63) / 64) + (size_t)n_long) * 3, 4);
+  const size_t bwd = 1024 + dc_part_bytes(nnz, D, n_long) + dc_part_bytes(nnz, D, n_tlong);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
+                                      const int32_t* col, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
+                                      const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, void* rec, float* sums,
+                                      void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !code || !rowptr || !sums || N <= 0 || nnz < 0 || (nnz > 0 && (!col || !rec))) return CEEG_EINVAL;
+  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (rec && !ceeg_aligned(rec, 16))) return CEEG_EINVAL;
+  if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_a >= sig_mod + (sig_mod == 1) || sig_b < 0 || sig_b >= sig_mod) return CEEG_EINVAL;
+  if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
+  if (max_row_nnz < 0 || (max_row_nnz > DC_CHUNK && n_long == 0)) return CEEG_EINVAL;  // hub rows need their piece list
+  if (ws_bytes < ceeg_decoder_codes_ws_bytes(N, nnz, n_e, D, n_long, 0) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* G = static_cast<float*>(ws);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + ceeg_ws_part((size_t)n_e * n_e, 4));
+  const int64_t nwave = (N + 63) / 64;
+  const int64_t nslot = nwave + n_long;
+  hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
+  CEEG_CHECK_LAUNCH();
+  uint4* r4 = static_cast<uint4*>(rec);
+  hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col, N, sig_a, sig_b,
+                     sig_mod, r4, part);
+  CEEG_CHECK_LAUNCH();
+  if (n_long > 0) {
+    hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col,
+                       reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, r4, part, nwave);
+    CEEG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nslot, sums);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                                      const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                                      int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
+                                      int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
+                                      float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0 || (nnz > 0 && (!t_perm || !rec))) return CEEG_EINVAL;
+  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) || (rec && !ceeg_aligned(rec, 16)))
+    return CEEG_EINVAL;
+  if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_b < 0 || sig_b >= sig_mod || sig_ainv <= 0) return CEEG_EINVAL;
+  if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)sig_mod) != (uint64_t)(1 % sig_mod)) return CEEG_EINVAL;
+  if (n_long < 0 || n_tlong < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16))) ||
+      (n_tlong > 0 && (!t_long_items || !ceeg_aligned(t_long_items, 16))))
+    return CEEG_EINVAL;
+  if (max_row_nnz < 0 || max_trow_nnz < 0 || (max_row_nnz > DC_CHUNK && n_long == 0) || (max_trow_nnz > DC_CHUNK && n_tlong == 0)) return CEEG_EINVAL;
+  if (ws_bytes < ceeg_decoder_codes_ws_bytes(N, nnz, n_e, D, n_long, n_tlong) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  DcGradArgs a;
+  a.W = W; a.ldw = ldw; a.K = n_e; a.D = D;
+  a.rowptr = rowptr; a.t_rowptr = t_rowptr; a.t_perm = t_perm;
+  a.rec = static_cast<const uint4*>(rec);
+  a.gscale = gscale; a.dz = dz; a.lddz = lddz; a.N = N; a.nnz = nnz;
+  a.sig_b = sig_b; a.sig_ainv = sig_ainv; a.sig_mod = sig_mod;
+  a.queue = static_cast<unsigned int*>(ws);
+  a.part_csr = reinterpret_cast<float*>(static_cast<char*>(ws) + 1024);
+  a.part_t = reinterpret_cast<float*>(static_cast<char*>(ws) + 1024 + dc_part_bytes(nnz, D, n_long));
+  if (hipMemsetAsync(ws, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
+  const int nslab = D / DC_CW;
+  const size_t lds = (size_t)n_e * DC_CW * 4;
+  auto grid_for = [&](int64_t groups_of_work) {  // workgroups: a multiple of nslab, at most one per CU
+    int64_t per_slab = (groups_of_work + (DC_GRAD_THREADS / 16) - 1) / (DC_GRAD_THREADS / 16);
+    if (per_slab < 1) per_slab = 1;
+    const int64_t cap = DC_MAX_GRAD_BLOCKS / nslab;
+    if (per_slab > cap) per_slab = cap;
+    return (unsigned)(per_slab * nslab);
+  };
+  if (n_long > 0) {
+    hipLaunchKernelGGL(dc_grad_long_kernel<false>, dim3(grid_for(n_long)), dim3(DC_GRAD_THREADS), lds, st, a,
+                       reinterpret_cast<const int4*>(long_items), n_long);
+    CEEG_CHECK_LAUNCH();
+  }
+  if (n_tlong > 0) {
+    hipLaunchKernelGGL(dc_grad_long_kernel<true>, dim3(grid_for(n_tlong)), dim3(DC_GRAD_THREADS), lds, st, a,
+                       reinterpret_cast<const int4*>(t_long_items), n_tlong);
+    CEEG_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(dc_grad_rows_kernel, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}

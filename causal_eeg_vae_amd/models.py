@@ -62,9 +62,35 @@ class CsrPair:
         self.max_row = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if N > 0 else 0
         self.max_trow = int((self.t_rowptr[1:] - self.t_rowptr[:-1]).max().item()) if N > 0 else 0
 
+        self._long = {}
+
     @property
     def device(self):
         return self.rowptr.device
+
+    def long_items(self, transposed=False):
+        """Piece list of the rows longer than ceeg_decoder_codes_chunk() entries (include/ceeg.h, ceeg_decoder_codes_*):
+        int32 [n][4] = (lo, hi, chunk*2 + slot, row), rows ascending, pieces ascending; None when no row is that long.
+        Static per graph: built once (graph-construction work, one host sync), never inside a step."""
+        key = bool(transposed)
+        if key not in self._long:
+            chunk = int(_lib.lib().ceeg_decoder_codes_chunk())
+            rp = (self.t_rowptr if transposed else self.rowptr).long()
+            rows = torch.nonzero((rp[1:] - rp[:-1]) > chunk).view(-1)
+            if rows.numel() == 0:
+                self._long[key] = None
+            else:
+                lo_r, hi_r = rp[rows], rp[rows + 1]
+                c_lo, c_hi = lo_r // chunk, (hi_r - 1) // chunk
+                cnt = c_hi - c_lo + 1
+                rid = torch.repeat_interleave(torch.arange(rows.numel(), device=rp.device), cnt)
+                first = torch.cumsum(cnt, 0) - cnt
+                c = c_lo[rid] + (torch.arange(rid.numel(), device=rp.device) - first[rid])
+                lo = torch.maximum(lo_r[rid], c * chunk)
+                hi = torch.minimum(hi_r[rid], (c + 1) * chunk)
+                slot = ((c == c_lo[rid]) & (lo_r[rid] != c * chunk)).long()
+                self._long[key] = torch.stack([lo, hi, c * 2 + slot, rows[rid]], dim=1).to(torch.int32).contiguous()
+        return self._long[key]
 
 
 class EventGraph:
@@ -422,17 +448,33 @@ class _FusedDecoder(torch.autograd.Function):
             src, sidx = z.contiguous(), None
         z = src
         p = graph.dec
-        coef = torch.empty(max(p.nnz, 1), 2, dtype=torch.float32, device=z.device)  # (d pos / dv, d neg / dv) per entry, interleaved
-        cp, cn = coef[:, 0], coef[:, 1]
         sums = torch.empty(3, dtype=torch.float32, device=z.device)
-        # with a gradient wanted, the forward also leaves the row-side halves of dz (two [N, D] tables)
-        grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
-        ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
-        with _lib.timed("decoder_fwd"):
-            _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
-                                                cp.data_ptr(), cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
-                                                sums.data_ptr(), p.max_row, ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
-        ctx.grow = grow
+        ctx.codes = (table is not None and os.environ.get("CEEG_DEC_CODES", "1") == "1"
+                     and L.ceeg_decoder_codes_supported(int(src.shape[0]), D) == 1)
+        if ctx.codes:
+            # code form: dots from the Gram matrix of the codebook, gradient from an LDS-resident codebook slab
+            li, lt = p.long_items(False), p.long_items(True)
+            ctx.items = (li, lt)
+            rec = torch.empty(max(p.nnz, 1), 4, dtype=torch.int32, device=z.device)
+            ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, src.shape[0], D, 0 if li is None else li.shape[0], 0), z.device)
+            with _lib.timed("decoder_fwd"):
+                _lib.check(L.ceeg_decoder_codes_fwd(src.data_ptr(), src.stride(0), src.shape[0], D, sidx.data_ptr(), p.rowptr.data_ptr(),
+                                                    p.col.data_ptr(), N, p.nnz, a, b, mod, _lib.ptr(li), 0 if li is None else li.shape[0],
+                                                    p.max_row, rec.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                           "ceeg_decoder_codes_fwd")
+            coef = rec
+            ctx.grow = None
+        else:
+            coef = torch.empty(max(p.nnz, 1), 2, dtype=torch.float32, device=z.device)  # (d pos / dv, d neg / dv) per entry, interleaved
+            cp, cn = coef[:, 0], coef[:, 1]
+            # with a gradient wanted, the forward also leaves the row-side halves of dz (two [N, D] tables)
+            grow = torch.empty(2, N, D, dtype=torch.float32, device=z.device) if (ctx.needs_input_grad[0] and row_sums) else None
+            ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
+            with _lib.timed("decoder_fwd"):
+                _lib.check(L.ceeg_decoder_fused_fwd(z.data_ptr(), z.stride(0), _lib.ptr(sidx), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz, D, a, b, mod,
+                                                    cp.data_ptr(), cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
+                                                    sums.data_ptr(), p.max_row, ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
+            ctx.grow = grow
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
         ctx.save_for_backward(z, coef, inv)
         ctx.sidx, ctx.shape = sidx, (N, D)
@@ -443,7 +485,6 @@ class _FusedDecoder(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _gs):
         z, coef, inv = ctx.saved_tensors
-        cp, cn = coef[:, 0], coef[:, 1]
         L = _lib.lib()
         N, D = ctx.shape
         p = ctx.graph.dec
@@ -451,6 +492,17 @@ class _FusedDecoder(torch.autograd.Function):
         a, b, ainv, mod = ctx.sig
         gscale = (inv * g).contiguous()
         dz = torch.empty(N, D, dtype=torch.float32, device=z.device)
+        if ctx.codes:
+            li, lt = ctx.items
+            nl, nt = (0 if li is None else li.shape[0]), (0 if lt is None else lt.shape[0])
+            ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, z.shape[0], D, nl, nt), z.device)
+            with _lib.timed("decoder_bwd"):
+                _lib.check(L.ceeg_decoder_codes_bwd(z.data_ptr(), z.stride(0), z.shape[0], D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(),
+                                                    p.t_perm.data_ptr(), N, p.nnz, a, b, ainv, mod, _lib.ptr(li), nl, _lib.ptr(lt), nt,
+                                                    p.max_row, p.max_trow, coef.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0),
+                                                    ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_codes_bwd")
+            return dz, None, None, None, None, None, None, None, None
+        cp, cn = coef[:, 0], coef[:, 1]
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         grow = ctx.grow
         with _lib.timed("decoder_bwd"):

@@ -200,6 +200,34 @@ int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, con
                            float* dz, int64_t lddz, int64_t max_row_nnz, int64_t max_trow_nnz,
                            void* ws, size_t ws_bytes, void* stream);
 
+/* Fused decoder for a QUANTISED latent, code form (the trainer's path when the decoder input is VectorQuantizer's z_q:
+ * z[n] = W[code[n]] bit for bit).  Same pairs, masks, terms and sums as ceeg_decoder_fused_fwd/_bwd (upstream PyG
+ * InnerProductDecoder + GAE.recon_loss, literal "+EPS" form), evaluated through the codebook:
+ *   forward : G = W W^T (n_e x n_e, k-ascending fmaf chains) once per call; <z_i, z_j> = G[code i][code j];
+ *             rec[p] = { cp[p], cn[p] (0 when the negative is masked), code[r] | code[sigma r] << 16, code[col p] }
+ *             for CSR entry p of row r (16 bytes, uint32 x 4; cp/cn as float bits); sums[0..2] as the fused decoder.
+ *   backward: dz[n] = gp*(sum_{p in row n} cp W[kc] + sum_{q in trow n} cp[tperm q] W[kr]) +
+ *                     gn*(sum_{p in row sigma^-1 n} cn W[kc] + sum_{q in trow n} cn[tperm q] W[ksr])
+ *             with a 64-column slab of the whole codebook resident in LDS (no global row gathers).
+ * Shapes: ceeg_decoder_codes_supported(n_e, D) != 0  <=>  n_e <= 576 and D in {64, 128, 192, 256}; code: int32 [N] in
+ * [0, n_e) (clamped).  Lists longer than ceeg_decoder_codes_chunk() (= 256) entries are cut at global positions
+ * k*256; the caller passes them as piece lists built once per graph: long_items / t_long_items, int32 [n][4] =
+ * (lo, hi, chunk*2 + slot, row) with slot = 1 for a piece that starts its row in the middle of a chunk, else 0
+ * (CSR rows resp. transposed rows; required when max_row_nnz / max_trow_nnz > 256, else NULL / 0).
+ * No counterpart in the reference beyond A6 itself; an algebraic re-association for the quantised case. */
+int ceeg_decoder_codes_chunk(void);
+int ceeg_decoder_codes_supported(int n_e, int D);
+size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);
+int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
+                           const int32_t* col, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
+                           const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, void* rec, float* sums,
+                           void* ws, size_t ws_bytes, void* stream);
+int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                           const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                           int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
+                           int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
+                           float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+
 /* Streaming helpers around the dense transform of a GCN layer (no counterpart of their own in the reference:
  * they stand where its host code calls torch.relu / autograd's ReLU backward / the bias-gradient reduction).
  *   ceeg_bias_relu       : y[n,:] = act(y[n,:] + bias) in place; bias may be NULL, relu != 0 applies max(.,0)

@@ -75,10 +75,14 @@ def test_config2_fused_decoder(config2):
         rec, sums = _FusedDecoder.apply(x, g, a, b, ainv, kw["row_sums"], None, *args)
         rec.backward()
         outs.append((rec.detach(), sums.detach(), x.grad))
-    for o in outs[1:3]:                                     # rerun and expanded-matrix form: bitwise
-        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
-    assert torch.equal(outs[3][0], outs[0][0])              # four-pass backward: same loss, gradient to rounding
-    torch.testing.assert_close(outs[3][2], outs[0][2], rtol=1e-4, atol=1e-9)
+    o = outs[1]                                             # rerun of the code form (Gram dots, LDS codebook slab): bitwise
+    assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+    # expanded-matrix form through the row-gather kernels: the same sums in another order
+    assert float(outs[2][1][2]) == float(outs[0][1][2])     # valid-negative count is exact
+    torch.testing.assert_close(outs[2][0], outs[0][0], rtol=1e-6, atol=0)
+    torch.testing.assert_close(outs[2][2], outs[0][2], rtol=1e-4, atol=1e-9)
+    assert torch.equal(outs[3][0], outs[2][0])              # four-pass backward: same loss, gradient to rounding
+    torch.testing.assert_close(outs[3][2], outs[2][2], rtol=1e-4, atol=1e-9)
     n_valid = int(outs[0][1][2])
     assert 0.99 * E < n_valid <= E                          # few permuted pairs collide with edges on a sparse graph
     assert float(outs[0][0]) > 0

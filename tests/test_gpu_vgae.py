@@ -219,11 +219,12 @@ def test_conditional_batched_step_vs_oracle(per_graph):
 
 
 @pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (1000, 30000, 32, 16)])
-def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e):
+def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e, monkeypatch):
     """Quantised latent passed as (codebook, int32 code per node): same loss, counts and gradient - bit for bit - as
     the expanded [N, D] matrix (include/ceeg.h, zidx of ceeg_decoder_fused_fwd / _bwd)."""
     from causal_eeg_vae_amd import EventGraph, sigma_params
     from causal_eeg_vae_amd.models import _FusedDecoder
+    monkeypatch.setenv("CEEG_DEC_CODES", "0")  # this test is about the zidx form of the row-gather kernels (decoder.hip)
     g = EventGraph(torch.from_numpy(_graph(N, E, 5)).cuda(), N)
     a_, b_, ainv = sigma_params(N, 1, 9)
     torch.manual_seed(3)
@@ -431,3 +432,91 @@ def test_edge_cases_empty_and_single():
         (loss + zq.sum()).backward()
         assert tuple(idx.shape) == (B, 1) and tuple(enc.shape) == (B, 16) and torch.isfinite(loss) and torch.isfinite(z.grad).all()
         assert torch.equal(zq.detach(), vq.embedding.weight[idx[:, 0]])
+
+
+def _codes_case(ei_np, N, D, n_e, sig, mod=None, seed=3):
+    """Quantised latent through (a) the code-form decoder (Gram-matrix dots, LDS-resident codebook slab), (b) the table
+    form of the row-gather kernels (CEEG_DEC_CODES=0) and (c) the oracle on the expanded matrix with explicit negatives."""
+    import os
+    from causal_eeg_vae_amd import EventGraph, _lib
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    from oracle import ref_torch
+    a_, b_, ainv = sig
+    g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    torch.manual_seed(seed)
+    W = (torch.randn(n_e, D) * (2.0 / D ** 0.5))
+    W[:3] *= 6  # a few saturated sigmoids: the literal +EPS form must match
+    idx = torch.randint(0, n_e, (N,), dtype=torch.int32)
+    zq = W[idx.long()]
+    assert _lib.lib().ceeg_decoder_codes_supported(n_e, D) == 1
+    outs = []
+    for env in ("1", "1", "0"):
+        os.environ["CEEG_DEC_CODES"] = env
+        try:
+            x = zq.clone().cuda().requires_grad_(True)
+            r, s = _FusedDecoder.apply(x, g, a_, b_, ainv, True, mod, W.cuda(), idx.cuda())
+            (r * 0.7).backward()
+            outs.append((r.detach(), s.clone(), x.grad.clone()))
+        finally:
+            os.environ.pop("CEEG_DEC_CODES", None)
+    (r1, s1, g1), (r2, s2, g2), (r0, s0, g0) = outs
+    assert torch.equal(r1, r2) and torch.equal(s1, s2) and torch.equal(g1, g2)     # bitwise reproducible
+    assert float(s1[2]) == float(s0[2])                                            # valid-negative count is exact
+    _close(s1, s0, rtol=1e-5)
+    _close(r1, r0, rtol=1e-5)
+    _close(g1, g0, rtol=1e-4, atol_rel=1e-5)
+    m = N if mod is None else mod
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    sig_rows = (rows - rows % m) + (a_ * (rows % m) + b_) % m
+    has = set(zip(col.tolist(), rows.tolist()))
+    valid = np.array([c != sr and (c, sr) not in has for c, sr in zip(col.tolist(), sig_rows.tolist())], dtype=bool)
+    assert int(s1[2].item()) == int(valid.sum())
+    a = zq.clone().requires_grad_(True)
+    pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
+    neg_ei = torch.from_numpy(np.stack([col, sig_rows]).astype(np.int64))[:, torch.from_numpy(valid)]
+    ref = ref_torch.recon_loss(a, pos_ei, neg_ei)
+    (ref * 0.7).backward()
+    _close(r1, ref, rtol=1e-5)
+    _close(g1, a.grad, rtol=1e-4, atol_rel=1e-5)
+
+
+@pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (2000, 30000, 64, 100), (1500, 20000, 256, 512), (900, 9000, 192, 7),
+                                       (64, 200, 128, 512), (65, 300, 64, 33)])
+def test_decoder_code_form(N, E, D, n_e):
+    from causal_eeg_vae_amd import sigma_params
+    _codes_case(_graph(N, E, N + D), N, D, n_e, sigma_params(N, 1, 9))
+
+
+def test_decoder_code_form_per_graph_blocks_and_hubs():
+    """sigma permuting inside equal-sized graphs of a collated batch; in-degree hubs (rows of 700 / 300 / 5000 entries) and
+    the out-degree hubs of the generator (transposed rows > 256 entries): every long list goes through the piece kernels."""
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    n, G = 500, 6
+    eis = [_graph(n, 6000, 100 + g) + g * n for g in range(G)]
+    _codes_case(np.concatenate(eis, axis=1), n * G, 128, 512, sigma_params(n, 4, 2), mod=n)
+    N = 6000
+    rng = np.random.default_rng(5)
+    base = _graph(N, 20000, 77)
+    hubs = [np.stack([rng.choice(N - 1, k, replace=False) + (1 if h == 0 else 0), np.full(k, h)]) for h, k in ((0, 700), (4000, 300), (5999, 5000))]
+    hubs = [hb[:, hb[0] != hb[1]] for hb in hubs]
+    ei_np = np.unique(np.concatenate([base] + hubs, axis=1), axis=1)
+    g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    assert g.dec.max_row > 256 and g.dec.max_trow > 256
+    assert g.dec.long_items(False) is not None and g.dec.long_items(True) is not None
+    _codes_case(ei_np, N, 128, 512, sigma_params(N, 2, 4))
+
+
+def test_decoder_code_form_degenerate():
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    empty = torch.zeros(2, 0, dtype=torch.int64, device="cuda")
+    for N in (1, 5):
+        g = EventGraph(empty, N)
+        W = torch.randn(16, 64, device="cuda")
+        idx = torch.zeros(N, dtype=torch.int32, device="cuda")
+        z = W[idx.long()].clone().requires_grad_(True)
+        a, b, ainv = sigma_params(N, 0, 0)
+        rec, sums = _FusedDecoder.apply(z, g, a, b, ainv, True, None, W, idx)
+        rec.backward()
+        assert float(rec.detach()) == 0.0 and float(sums.abs().sum()) == 0.0 and float(z.grad.abs().sum()) == 0.0
