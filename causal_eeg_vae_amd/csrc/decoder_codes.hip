@@ -44,6 +44,11 @@ struct DcGradArgs {
   float* part_t;     // [chunk*2+slot][2][D]: pieces of long transposed rows (sum 0: cp W[kr], sum 1: cn W[ksr])
 };
 
+struct DcNode {  // one pipeline stage of dc_grad_rows_kernel: a node's three lists and their first batches
+  int A_lo, A_hi, a_hi, B_lo, B_hi, b_hi, C_lo, C_hi, c_hi, tp;
+  uint4 ra, rb, rc;
+};
+
 template <int T>
 __device__ __forceinline__ int dc_bcast(int v) {  // lane T of the caller's 16-lane DPP row, in every lane of that row
   return __builtin_amdgcn_update_dpp(0, v, 0x150 + T, 0xf, 0xf, false);
@@ -236,25 +241,30 @@ __device__ __forceinline__ void dc_fma4(float c, const float4& x, float4& s) {
   s.w = __fmaf_rn(c, x.w, s.w);
 }
 
-// one batch: the group's lanes hold (cf, k) of up to 16 entries (n live; the others carry cf = 0, k = 0): s += sum_t cf_t W[k_t]
-__device__ __forceinline__ void dc_batch1(const float4* lds4, int gl, float cf, int k, int n, float4& s) {
-  do {
-#define DC_STEP(T)                              \
-    if (!__any(n > T)) break;                   \
+// one batch: the group's lanes hold (cf, k) of up to 16 entries (n live; the others carry cf = 0, k = 0, which add 0 * W[0]):
+// s += sum_t cf_t W[k_t].  Steps run in blocks of 4 with one wave-uniform early-out per block, so the four LDS reads of a
+// block are in flight together (a branch per step serialised them: read -> wait -> fma).
+#define DC_STEP1(T)                             \
     {                                           \
       const float ct = dc_bcastf<T>(cf);        \
       const int kt = dc_bcast<T>(k);            \
       dc_fma4(ct, lds4[kt * 16 + gl], s);       \
     }
-    DC_FOR16(DC_STEP)
-#undef DC_STEP
+__device__ __forceinline__ void dc_batch1(const float4* lds4, int gl, float cf, int k, int n, float4& s) {
+  do {
+    if (!__any(n > 0)) break;
+    DC_STEP1(0) DC_STEP1(1) DC_STEP1(2) DC_STEP1(3)
+    if (!__any(n > 4)) break;
+    DC_STEP1(4) DC_STEP1(5) DC_STEP1(6) DC_STEP1(7)
+    if (!__any(n > 8)) break;
+    DC_STEP1(8) DC_STEP1(9) DC_STEP1(10) DC_STEP1(11)
+    if (!__any(n > 12)) break;
+    DC_STEP1(12) DC_STEP1(13) DC_STEP1(14) DC_STEP1(15)
   } while (0);
 }
+#undef DC_STEP1
 // the same with two (coefficient, code) pairs per entry and two sums
-__device__ __forceinline__ void dc_batch2(const float4* lds4, int gl, float ca, int ka, float cb, int kb, int n, float4& sa, float4& sb) {
-  do {
-#define DC_STEP(T)                                        \
-    if (!__any(n > T)) break;                             \
+#define DC_STEP2(T)                                       \
     {                                                     \
       const float at = dc_bcastf<T>(ca);                  \
       const int kat = dc_bcast<T>(ka);                    \
@@ -263,10 +273,19 @@ __device__ __forceinline__ void dc_batch2(const float4* lds4, int gl, float ca, 
       dc_fma4(at, lds4[kat * 16 + gl], sa);               \
       dc_fma4(bt, lds4[kbt * 16 + gl], sb);               \
     }
-    DC_FOR16(DC_STEP)
-#undef DC_STEP
+__device__ __forceinline__ void dc_batch2(const float4* lds4, int gl, float ca, int ka, float cb, int kb, int n, float4& sa, float4& sb) {
+  do {
+    if (!__any(n > 0)) break;
+    DC_STEP2(0) DC_STEP2(1) DC_STEP2(2) DC_STEP2(3)
+    if (!__any(n > 4)) break;
+    DC_STEP2(4) DC_STEP2(5) DC_STEP2(6) DC_STEP2(7)
+    if (!__any(n > 8)) break;
+    DC_STEP2(8) DC_STEP2(9) DC_STEP2(10) DC_STEP2(11)
+    if (!__any(n > 12)) break;
+    DC_STEP2(12) DC_STEP2(13) DC_STEP2(14) DC_STEP2(15)
   } while (0);
 }
+#undef DC_STEP2
 
 __device__ __forceinline__ void dc_fill_slab(const DcGradArgs& a, int slab, float4* lds4) {
   for (int i = threadIdx.x; i < a.K * 16; i += DC_GRAD_THREADS)
@@ -313,56 +332,74 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       chi = a.t_rowptr[n + 1];
     }
     const int cnt = a.N - base_n < 64 ? (int)(a.N - base_n) : 64;
+    // Three-stage pipeline over the draw's iterations (4 nodes each): while iteration `it` computes, the records of
+    // it+1 are in flight (their t_perm entries were fetched an iteration earlier) and the t_perm entries of it+2 are issued.
+    DcNode s0, s1, s2;
+    auto bounds = [&](int it, DcNode& s) {
+      const int j = (it * 4 + grp) & 63;
+      const bool ok = it * 4 < cnt;  // wave-uniform
+      s.A_lo = __shfl(alo, j, 64); s.A_hi = __shfl(ahi, j, 64);
+      s.B_lo = __shfl(blo, j, 64); s.B_hi = __shfl(bhi, j, 64);
+      s.C_lo = __shfl(clo, j, 64); s.C_hi = __shfl(chi, j, 64);
+      if (!ok) { s.A_hi = s.A_lo; s.B_hi = s.B_lo; s.C_hi = s.C_lo; }
+      s.a_hi = s.A_hi - s.A_lo > DC_CHUNK ? s.A_lo : s.A_hi;  // long lists: their pieces come from dc_grad_long_kernel
+      s.b_hi = s.B_hi - s.B_lo > DC_CHUNK ? s.B_lo : s.B_hi;
+      s.c_hi = s.C_hi - s.C_lo > DC_CHUNK ? s.C_lo : s.C_hi;
+      s.tp = 0;
+      if (s.C_lo + gl < s.c_hi) s.tp = a.t_perm[s.C_lo + gl];
+    };
+    auto records = [&](DcNode& s) {  // first batches of the three lists
+      s.ra = zero4; s.rb = zero4; s.rc = zero4;
+      if (s.C_lo + gl < s.c_hi) s.rc = a.rec[s.tp];
+      if (s.A_lo + gl < s.a_hi) s.ra = a.rec[s.A_lo + gl];
+      if (s.B_lo + gl < s.b_hi) s.rb = a.rec[s.B_lo + gl];
+    };
+    bounds(0, s0);
+    bounds(1, s1);
+    records(s0);
     for (int it = 0; it * 4 < cnt; ++it) {
+      bounds(it + 2, s2);
+      records(s1);
       const int j = it * 4 + grp;
-      const int A_lo = __shfl(alo, j, 64), A_hi = __shfl(ahi, j, 64);
-      const int B_lo = __shfl(blo, j, 64), B_hi = __shfl(bhi, j, 64);
-      const int C_lo = __shfl(clo, j, 64), C_hi = __shfl(chi, j, 64);
-      const bool a_long = A_hi - A_lo > DC_CHUNK, b_long = B_hi - B_lo > DC_CHUNK, c_long = C_hi - C_lo > DC_CHUNK;
-      const int a_hi = a_long ? A_lo : A_hi, b_hi = b_long ? B_lo : B_hi, c_hi = c_long ? C_lo : C_hi;
-      // first batches of the three lists: the dependent chain (t_perm -> rec) first, then the two streamed ones
-      int tp = 0;
-      if (C_lo + gl < c_hi) tp = a.t_perm[C_lo + gl];
-      uint4 ra = zero4, rb = zero4, rc = zero4;
-      if (A_lo + gl < a_hi) ra = a.rec[A_lo + gl];
-      if (B_lo + gl < b_hi) rb = a.rec[B_lo + gl];
-      if (C_lo + gl < c_hi) rc = a.rec[tp];
-      float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1, s3 = s1, s4 = s1;
+      uint4 ra = s0.ra, rb = s0.rb, rc = s0.rc;
+      float4 s1v = make_float4(0.f, 0.f, 0.f, 0.f), s2v = s1v, s3v = s1v, s4v = s1v;
       // (1) n as destination of positives: sum_{p in row n} cp W[kc]
-      for (int base = A_lo; __any(base < a_hi); base += 16) {
-        if (base != A_lo) { ra = zero4; if (base + gl < a_hi) ra = a.rec[base + gl]; }
-        const int nb = a_hi - base;
-        dc_batch1(lds4, gl, __uint_as_float(ra.x), (int)ra.w, nb < 0 ? 0 : nb, s1);
+      for (int base = s0.A_lo; __any(base < s0.a_hi); base += 16) {
+        if (base != s0.A_lo) { ra = zero4; if (base + gl < s0.a_hi) ra = a.rec[base + gl]; }
+        const int nb = s0.a_hi - base;
+        dc_batch1(lds4, gl, __uint_as_float(ra.x), (int)ra.w, nb < 0 ? 0 : nb, s1v);
       }
       // (3) n as negative endpoint sigma(m): sum_{p in row m} cn W[kc]
-      for (int base = B_lo; __any(base < b_hi); base += 16) {
-        if (base != B_lo) { rb = zero4; if (base + gl < b_hi) rb = a.rec[base + gl]; }
-        const int nb = b_hi - base;
-        dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3);
+      for (int base = s0.B_lo; __any(base < s0.b_hi); base += 16) {
+        if (base != s0.B_lo) { rb = zero4; if (base + gl < s0.b_hi) rb = a.rec[base + gl]; }
+        const int nb = s0.b_hi - base;
+        dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3v);
       }
       // (2) + (4) n as source: sum_q cp W[kr], sum_q cn W[ksr] over the transposed row
-      for (int base = C_lo; __any(base < c_hi); base += 16) {
-        if (base != C_lo) {
+      for (int base = s0.C_lo; __any(base < s0.c_hi); base += 16) {
+        if (base != s0.C_lo) {
           rc = zero4;
-          if (base + gl < c_hi) rc = a.rec[a.t_perm[base + gl]];
+          if (base + gl < s0.c_hi) rc = a.rec[a.t_perm[base + gl]];
         }
-        const int nb = c_hi - base;
-        dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2, s4);
+        const int nb = s0.c_hi - base;
+        dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2v, s4v);
       }
-      if (a_long) dc_add_pieces(a.part_csr, A_lo, A_hi, 0, a.D, col0, s1);
-      if (b_long) dc_add_pieces(a.part_csr, B_lo, B_hi, 1, a.D, col0, s3);
-      if (c_long) {
-        dc_add_pieces(a.part_t, C_lo, C_hi, 0, a.D, col0, s2);
-        dc_add_pieces(a.part_t, C_lo, C_hi, 1, a.D, col0, s4);
+      if (s0.A_hi != s0.a_hi) dc_add_pieces(a.part_csr, s0.A_lo, s0.A_hi, 0, a.D, col0, s1v);
+      if (s0.B_hi != s0.b_hi) dc_add_pieces(a.part_csr, s0.B_lo, s0.B_hi, 1, a.D, col0, s3v);
+      if (s0.C_hi != s0.c_hi) {
+        dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 0, a.D, col0, s2v);
+        dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 1, a.D, col0, s4v);
       }
       if (j < cnt) {
         float4 o;
-        o.x = gn * (s3.x + s4.x) + gp * (s1.x + s2.x);
-        o.y = gn * (s3.y + s4.y) + gp * (s1.y + s2.y);
-        o.z = gn * (s3.z + s4.z) + gp * (s1.z + s2.z);
-        o.w = gn * (s3.w + s4.w) + gp * (s1.w + s2.w);
+        o.x = gn * (s3v.x + s4v.x) + gp * (s1v.x + s2v.x);
+        o.y = gn * (s3v.y + s4v.y) + gp * (s1v.y + s2v.y);
+        o.z = gn * (s3v.z + s4v.z) + gp * (s1v.z + s2v.z);
+        o.w = gn * (s3v.w + s4v.w) + gp * (s1v.w + s2v.w);
         *reinterpret_cast<float4*>(a.dz + (base_n + j) * a.lddz + col0) = o;
       }
+      s0 = s1;
+      s1 = s2;
     }
   }
 }
