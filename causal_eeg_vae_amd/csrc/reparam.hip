@@ -173,6 +173,106 @@ __global__ __launch_bounds__(RP_THREADS) void reparam_kl_bwd_kernel(
   }
 }
 
+// ------------------------------------------------------------------ fused: VQ dz + reparam backward + column sums
+// The backward of  z = reparametrize(mu, logstd);  (loss_vq, z_q) = VectorQuantizer(z)  in one pass over the rows:
+//   gz  = g_zq + g_z + s * (2 / (N D)) * (z - W[idx])      (ceeg_vq_backward's dz; z is RECOMPUTED from mu, logstd, eps)
+//   dmu, dlogstd = reparam backward of gz and gkl          (rp_bwd_elem, same arithmetic as reparam_kl_bwd_kernel)
+//   part[block][0:D | D:2D] = column sums of dmu | dlogstd over the block's rows  (the head GCNConv's bias gradient)
+// Block b owns rows [b*rows_per, ...); thread t owns column quad t % (D/4) and walks rows t / (D/4), + RP_THREADS/(D/4), ...
+__global__ __launch_bounds__(RP_THREADS) void reparam_vq_bwd_kernel(
+    const float* __restrict__ mu, int64_t ld_mu, const float* __restrict__ logstd, int64_t ld_ls, const float* __restrict__ eps,
+    uint64_t seed, const float* __restrict__ g_zq, const float* __restrict__ g_z, const float* __restrict__ W,
+    const int64_t* __restrict__ idx, int n_e, const float* __restrict__ s_dev, const float* __restrict__ gkl_dev, int64_t N, int D,
+    float max_ls, int log_var, int training, float* __restrict__ dmu, int64_t ld_dmu, float* __restrict__ dls, int64_t ld_dls,
+    int64_t rows_per, float* __restrict__ part /* [grid][2D] or NULL */) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* red = reinterpret_cast<float4*>(smem);  // [2][RP_THREADS]
+  const int dq = D / 4;
+  const int rpb = RP_THREADS / dq;
+  const int cq = threadIdx.x % dq, rr = threadIdx.x / dq;
+  const int d = 4 * cq;
+  const float gkl_n = gkl_dev ? gkl_dev[0] / (float)N : 0.f;
+  const float coef = s_dev ? s_dev[0] * (2.0f / ((float)N * (float)D)) : 0.f;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per;
+  const int64_t hi = lo + rows_per < N ? lo + rows_per : N;
+  float4 am = make_float4(0.f, 0.f, 0.f, 0.f), al = am;
+  if (rr < rpb) {
+    for (int64_t n = lo + rr; n < hi; n += rpb) {
+      const float4 m = *reinterpret_cast<const float4*>(mu + n * ld_mu + d);
+      const float4 l = *reinterpret_cast<const float4*>(logstd + n * ld_ls + d);
+      int64_t k = idx[n];
+      k = k < 0 ? 0 : (k >= n_e ? n_e - 1 : k);
+      const float4 w = *reinterpret_cast<const float4*>(W + k * D + d);
+      float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g_zq) go = *reinterpret_cast<const float4*>(g_zq + n * D + d);
+      float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (training) {
+        if (eps) {
+          e = *reinterpret_cast<const float4*>(eps + n * D + d);
+        } else {
+          const int64_t g = n * dq + cq;
+          const uint4 x = ceeg_philox(seed, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), CEEG_TAG_EPS, 0u);
+          const float2 a = ceeg_box_muller(x.x, x.y), b = ceeg_box_muller(x.z, x.w);
+          e = make_float4(a.x, a.y, b.x, b.y);
+        }
+      }
+      float4 z;
+      float t;
+      rp_fwd_elem(m.x, l.x, e.x, max_ls, log_var, training, z.x, t);
+      rp_fwd_elem(m.y, l.y, e.y, max_ls, log_var, training, z.y, t);
+      rp_fwd_elem(m.z, l.z, e.z, max_ls, log_var, training, z.z, t);
+      rp_fwd_elem(m.w, l.w, e.w, max_ls, log_var, training, z.w, t);
+      float4 gz;  // as vq_dz4_kernel: coef * (z - w), then + g
+      gz.x = coef * (z.x - w.x) + go.x; gz.y = coef * (z.y - w.y) + go.y;
+      gz.z = coef * (z.z - w.z) + go.z; gz.w = coef * (z.w - w.w) + go.w;
+      if (g_z) {
+        const float4 h = *reinterpret_cast<const float4*>(g_z + n * D + d);
+        gz.x += h.x; gz.y += h.y; gz.z += h.z; gz.w += h.w;
+      }
+      float4 om, ol;
+      rp_bwd_elem(m.x, l.x, e.x, gz.x, gkl_n, max_ls, log_var, training, om.x, ol.x);
+      rp_bwd_elem(m.y, l.y, e.y, gz.y, gkl_n, max_ls, log_var, training, om.y, ol.y);
+      rp_bwd_elem(m.z, l.z, e.z, gz.z, gkl_n, max_ls, log_var, training, om.z, ol.z);
+      rp_bwd_elem(m.w, l.w, e.w, gz.w, gkl_n, max_ls, log_var, training, om.w, ol.w);
+      *reinterpret_cast<float4*>(dmu + n * ld_dmu + d) = om;
+      *reinterpret_cast<float4*>(dls + n * ld_dls + d) = ol;
+      am.x += om.x; am.y += om.y; am.z += om.z; am.w += om.w;
+      al.x += ol.x; al.y += ol.y; al.z += ol.z; al.w += ol.w;
+    }
+  }
+  if (part == nullptr) return;
+  red[threadIdx.x] = am;
+  red[RP_THREADS + threadIdx.x] = al;
+  __syncthreads();
+  if (rr == 0) {  // fixed order over the block's row groups
+    for (int k = 1; k < rpb; ++k) {
+      const float4 t1 = red[k * dq + cq], t2 = red[RP_THREADS + k * dq + cq];
+      am.x += t1.x; am.y += t1.y; am.z += t1.z; am.w += t1.w;
+      al.x += t2.x; al.y += t2.y; al.z += t2.z; al.w += t2.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 2 * D + d) = am;
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 2 * D + D + d) = al;
+  }
+}
+
+// column f of out = fp64 sum over the block partials in a fixed interleave (16 thread groups), as elementwise.hip
+__global__ __launch_bounds__(256) void reparam_colsum_finalize_kernel(const float* __restrict__ part, int nblk, int F, float* __restrict__ out) {
+  __shared__ double red[256];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + c;
+  double s = 0.0;
+  if (f < F)
+    for (int b = grp; b < nblk; b += 16) s += (double)part[(size_t)b * F + f];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (grp == 0 && f < F) {
+    for (int k = 1; k < 16; ++k) s += red[k * 16 + c];
+    out[f] = (float)s;
+  }
+}
+
+constexpr int RP_FUSED_MAX_BLOCKS = 2048;
+
 int rp_blocks(int64_t work) {
   int64_t b = (work + RP_THREADS - 1) / RP_THREADS;
   if (b < 1) b = 1;
@@ -218,5 +318,37 @@ extern "C" int ceeg_reparam_kl_bwd(const float* mu, int64_t ld_mu, const float* 
   hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(nblk), dim3(RP_THREADS), 0, st, mu, ld_mu, logstd, ld_ls, eps, seed, gz, gkl_dev, N, D,
                      max_logstd, log_var, training, vec, dmu, ld_dmu, dlogstd, ld_dls);
   CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" size_t ceeg_reparam_vq_bwd_ws_bytes(int64_t N, int D) {
+  if (N <= 0 || D <= 0) return 0;
+  return ceeg_ws_part((size_t)RP_FUSED_MAX_BLOCKS * 2 * D, 4);
+}
+
+extern "C" int ceeg_reparam_vq_bwd(const float* mu, int64_t ld_mu, const float* logstd, int64_t ld_ls, const float* eps, uint64_t seed,
+                                   const float* g_zq, const float* g_z, const float* W, const int64_t* idx, int n_e,
+                                   const float* s_dev, const float* gkl_dev, int64_t N, int D, float max_logstd, int log_var,
+                                   int training, float* dmu, int64_t ld_dmu, float* dlogstd, int64_t ld_dls, float* colsum,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  if (!mu || !logstd || !W || !idx || !dmu || !dlogstd || N <= 0 || D <= 0 || n_e <= 0) return CEEG_EINVAL;
+  if (ld_mu < D || ld_ls < D || ld_dmu < D || ld_dls < D) return CEEG_EINVAL;
+  if ((D % 4) != 0 || D > 4 * RP_THREADS) return CEEG_EUNSUPPORTED;
+  if (!(rp_vec_ok(D, ld_mu, ld_ls, mu, logstd, eps, g_zq) && rp_vec_ok(D, ld_dmu, ld_dls, dmu, dlogstd, g_z, W))) return CEEG_EUNSUPPORTED;
+  if (colsum && (ws_bytes < ceeg_reparam_vq_bwd_ws_bytes(N, D) || !ws || !ceeg_aligned(ws, 256))) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t nblk = (N + 127) / 128;
+  if (nblk > RP_FUSED_MAX_BLOCKS) nblk = RP_FUSED_MAX_BLOCKS;
+  const int64_t rows_per = (N + nblk - 1) / nblk;
+  nblk = (N + rows_per - 1) / rows_per;
+  float* part = colsum ? static_cast<float*>(ws) : nullptr;
+  hipLaunchKernelGGL(reparam_vq_bwd_kernel, dim3((unsigned)nblk), dim3(RP_THREADS), 2 * RP_THREADS * 16, st, mu, ld_mu, logstd, ld_ls, eps,
+                     seed, g_zq, g_z, W, idx, n_e, s_dev, gkl_dev, N, D, max_logstd, log_var, training, dmu, ld_dmu, dlogstd, ld_dls,
+                     rows_per, part);
+  CEEG_CHECK_LAUNCH();
+  if (colsum) {
+    hipLaunchKernelGGL(reparam_colsum_finalize_kernel, dim3((2 * D + 15) / 16), dim3(256), 0, st, part, (int)nblk, 2 * D, colsum);
+    CEEG_CHECK_LAUNCH();
+  }
   return CEEG_OK;
 }

@@ -167,6 +167,24 @@ def _relu_bwd_colsum(g, y):
     return gm, out
 
 
+# Column sums a producer kernel already holds for a gradient tensor it is about to hand to autograd (the fused
+# reparam + VQ backward leaves the head's bias gradient): keyed by the tensor's storage pointer, consumed once.
+_COLSUM_HINT = {}
+
+
+def _offer_colsum(t, colsum):
+    import weakref
+    _COLSUM_HINT.clear()
+    _COLSUM_HINT[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), colsum)
+
+
+def _take_colsum(t):
+    ent = _COLSUM_HINT.pop(t.data_ptr(), None)
+    if ent is None or ent[0]() is None or ent[1] != tuple(t.shape) or not t.is_contiguous():
+        return None
+    return ent[2]
+
+
 class _GcnAggregate(torch.autograd.Function):
     """out = act(A_hat @ h + b); backward dh = A_hat^T @ g through the transposed CSR (values via t_perm)."""
 
@@ -189,7 +207,9 @@ class _GcnAggregate(torch.autograd.Function):
             (out,) = ctx.saved_tensors
             grad, dbias = _relu_bwd_colsum(grad, out)
         else:
-            dbias = _colsum(grad) if ctx.has_bias else None
+            dbias = (_take_colsum(grad) if ctx.has_bias else None)
+            if dbias is None and ctx.has_bias:
+                dbias = _colsum(grad)
         dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
@@ -332,6 +352,89 @@ class _ReparamKL(torch.autograd.Function):
         if ctx.fused:
             return dml, None, None, None, None, None
         return dml[:, :D], dml[:, D:], None, None, None, None
+
+
+class _ReparamVQ(torch.autograd.Function):
+    """(z, kl, vq_loss, z_q, perplexity, idx) = VectorQuantizer(reparametrize(mu | logstd)) with ONE fused backward pass
+    (ceeg_reparam_vq_bwd): dz of the quantiser is never written, z is recomputed from (mu, logstd, eps/seed), and the
+    column sums of the [N, 2D] gradient (the encoder head's bias gradient) come out of the same pass.
+    `ml` is the fused [N, 2D] encoder output (mu | logstd); forward = ceeg_reparam_kl_fwd + ceeg_vq_forward as
+    _ReparamKL / _VQFunction (scripts/models.py:30-32 order: encoder -> latent -> vector_quantization)."""
+
+    @staticmethod
+    def forward(ctx, ml, eps, seed, training, log_var, weight, beta):
+        _lib.require_cuda(ml, weight)
+        L = _lib.lib()
+        ml = ml.contiguous()
+        N, D = ml.shape[0], ml.shape[1] // 2
+        mu_v, ls_v = ml[:, :D], ml[:, D:]
+        dev = ml.device
+        epsc = None if eps is None else eps.contiguous()
+        wc = weight.contiguous()
+        n_e = wc.shape[0]
+        if wc.shape[1] != D or wc.dtype != torch.float32:
+            raise ValueError("the codebook must be float32 [n_e, latent]")
+        z = torch.empty(N, D, dtype=torch.float32, device=dev)
+        kl = torch.empty((), dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.ceeg_reparam_kl_ws_bytes(N, D), dev)
+        _lib.check(L.ceeg_reparam_kl_fwd(mu_v.data_ptr(), mu_v.stride(0), ls_v.data_ptr(), ls_v.stride(0), _lib.ptr(epsc), int(seed),
+                                         N, D, float(MAX_LOGSTD), int(log_var), int(training), z.data_ptr(), kl.data_ptr(),
+                                         ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_kl_fwd")
+        z_q = torch.empty_like(z)
+        idx = torch.empty(N, 1, dtype=torch.int64, device=dev)
+        scal = torch.empty(2, dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.ceeg_vq_forward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
+        _lib.check(L.ceeg_vq_forward(z.data_ptr(), wc.data_ptr(), N, n_e, D, _lib.CEEG_F32, float(beta), z_q.data_ptr(), idx.data_ptr(),
+                                     scal[0:].data_ptr(), scal[1:].data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream()),
+                   "ceeg_vq_forward")
+        ctx.save_for_backward(ml, epsc, wc, idx, z)
+        ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
+        ctx.mark_non_differentiable(scal[1], idx)
+        return z, kl, scal[0], z_q, scal[1], idx
+
+    @staticmethod
+    def backward(ctx, g_z, g_kl, g_loss, g_zq, _g_ppl, _g_idx):
+        ml, epsc, wc, idx, z = ctx.saved_tensors
+        seed, training, log_var, beta = ctx.cfg
+        L = _lib.lib()
+        N, D = z.shape
+        n_e = wc.shape[0]
+        dev = z.device
+        s = None if g_loss is None else g_loss.reshape(1).to(torch.float32).contiguous()
+        gk = None if g_kl is None else g_kl.reshape(1).contiguous()
+        dW = None
+        if ctx.needs_input_grad[5]:
+            dW = torch.empty_like(wc)
+            sw = s if s is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+            ws = _lib.workspace(L.ceeg_vq_backward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
+            _lib.check(L.ceeg_vq_backward(z.data_ptr(), wc.data_ptr(), idx.data_ptr(), None, sw.data_ptr(), N, n_e, D, _lib.CEEG_F32, beta,
+                                          None, dW.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_vq_backward")
+        dml = None
+        if ctx.needs_input_grad[0]:
+            dml = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+            colsum = torch.empty(2 * D, dtype=torch.float32, device=dev)
+            gq = None if g_zq is None else g_zq.contiguous()
+            gz = None if g_z is None else g_z.contiguous()
+            ws = _lib.workspace(L.ceeg_reparam_vq_bwd_ws_bytes(N, D), dev)
+            with _lib.timed("reparam_vq_bwd"):
+                _lib.check(L.ceeg_reparam_vq_bwd(ml.data_ptr(), ml.stride(0), ml[:, D:].data_ptr(), ml.stride(0), _lib.ptr(epsc), seed,
+                                                 _lib.ptr(gq), _lib.ptr(gz), wc.data_ptr(), idx.data_ptr(), n_e, _lib.ptr(s), _lib.ptr(gk),
+                                                 N, D, float(MAX_LOGSTD), log_var, training, dml.data_ptr(), 2 * D, dml[:, D:].data_ptr(),
+                                                 2 * D, colsum.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_vq_bwd")
+            _offer_colsum(dml, colsum)
+        return dml, None, None, None, None, dW, None
+
+
+def _reparam_vq(ml, eps, seed, training, vq):
+    """reparametrise + KL + VectorQuantizer on the fused [N, 2D] encoder output; the fused-backward form when the shapes
+    allow it (fp32, latent % 4 == 0), else the two separate autograd functions."""
+    D = ml.shape[1] // 2
+    if D % 4 == 0 and os.environ.get("CEEG_FUSED_RVQ", "1") == "1":
+        z, kl, vq_loss, z_q, ppl, idx = _ReparamVQ.apply(ml, eps, seed, training, False, vq.embedding.weight, vq.beta)
+        return z, kl, vq_loss, z_q, ppl, idx
+    z, kl = _ReparamKL.apply(ml, None, eps, seed, training, False)
+    vq_loss, z_q, ppl, _, idx = vq(z)
+    return z, kl, vq_loss, z_q, ppl, idx
 
 
 def _edge_lists_i32(edge_index):
@@ -604,8 +707,7 @@ class VGAEVQ(nn.Module):
         ml = self.encoder.forward_fused(x, graph)
         D = self.latent
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
-        z, kl = _ReparamKL.apply(ml, None, eps, seed, self.training, False)
-        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, seed, self.training, self.vector_quantization)
         a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
         # z_q is bit-for-bit codebook[idx] in fp32: let the decoder gather 512 codebook rows through idx
         rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, None, self.vector_quantization.embedding.weight,
@@ -639,8 +741,7 @@ class ConditionalVGAEVQ(nn.Module):
         cn = condition.index_select(0, batch)  # c[batch]
         ml = self.encoder.forward_fused(torch.cat((x, cn), dim=1), graph)
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
-        z, kl = _ReparamKL.apply(ml, None, eps, seed, self.training, False)
-        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, seed, self.training, self.vector_quantization)
         mod = N if nodes_per_graph is None else int(nodes_per_graph)
         if N % mod:
             raise ValueError("nodes_per_graph must divide the number of nodes of the batch")

@@ -142,6 +142,20 @@ int ceeg_reparam_kl_bwd(const float* mu, int64_t ld_mu, const float* logstd, int
                         float max_logstd, int log_var, int training,
                         float* dmu, int64_t ld_dmu, float* dlogstd, int64_t ld_dls, void* stream);
 
+/* Fused backward of the pair  z = reparametrize(mu, logstd);  (loss_vq, z_q) = VectorQuantizer(z)  (the order
+ * BaseCVAE.forward uses, scripts/models.py:30-32): one pass computes
+ *   gz = g_zq + g_z + s*(2/(N*D))*(z - W[idx])     (ceeg_vq_backward's dz with z recomputed from mu, logstd, eps/seed)
+ *   dmu, dlogstd = ceeg_reparam_kl_bwd(gz, gkl)     (bitwise equal to running the two entry points one after the other)
+ *   colsum[0:D | D:2D] = column sums of dmu | dlogstd (optional: the bias gradient of the encoder head; fixed order)
+ * so dz is never written or re-read.  g_zq / g_z: [N,D] fp32 or NULL; s_dev / gkl_dev: 1 float on the device or NULL;
+ * idx: int64 [N]; D % 4 == 0, 16-byte aligned operands.  The codebook gradient stays with ceeg_vq_backward (dz = NULL). */
+size_t ceeg_reparam_vq_bwd_ws_bytes(int64_t N, int D);
+int ceeg_reparam_vq_bwd(const float* mu, int64_t ld_mu, const float* logstd, int64_t ld_ls, const float* eps, uint64_t seed,
+                        const float* g_zq, const float* g_z, const float* W, const int64_t* idx, int n_e,
+                        const float* s_dev, const float* gkl_dev, int64_t N, int D, float max_logstd, int log_var,
+                        int training, float* dmu, int64_t ld_dmu, float* dlogstd, int64_t ld_dls, float* colsum,
+                        void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A6  InnerProductDecoder.forward + GAE.recon_loss (upstream PyG), literal "+EPS" form, EPS = 1e-15:
  *   v_e = <z[i_e], z[j_e]> ; pos: -log(sigmoid(v)+EPS) ; neg: -log(1-sigmoid(v)+EPS)

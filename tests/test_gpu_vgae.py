@@ -520,3 +520,42 @@ def test_decoder_code_form_degenerate():
         rec, sums = _FusedDecoder.apply(z, g, a, b, ainv, True, None, W, idx)
         rec.backward()
         assert float(rec.detach()) == 0.0 and float(sums.abs().sum()) == 0.0 and float(z.grad.abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("N,D,n_e,with_eps", [(5000, 128, 512, False), (777, 32, 40, True), (300, 256, 512, False), (1, 8, 4, True)])
+def test_fused_reparam_vq_backward_equals_the_two_steps(N, D, n_e, with_eps, monkeypatch):
+    """ceeg_reparam_vq_bwd (dz of the quantiser never written, z recomputed, bias column sums in the same pass) gives the
+    gradient of ceeg_vq_backward followed by ceeg_reparam_kl_bwd bit for bit; its column sums equal the gradient's."""
+    from causal_eeg_vae_amd import VectorQuantizer
+    from causal_eeg_vae_amd.models import _reparam_vq, _take_colsum
+    torch.manual_seed(N + D)
+    ml0 = torch.randn(N, 2 * D, device="cuda")
+    ml0[::5, D:] = 10.7   # clamped rows: zero logstd gradient
+    eps = torch.randn(N, D, device="cuda") if with_eps else None
+    vq = VectorQuantizer(n_e, D, 0.25, return_one_hot=False).cuda()
+    with torch.no_grad():
+        vq.embedding.weight.normal_()
+    r = torch.randn(N, D, device="cuda")
+    outs = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CEEG_FUSED_RVQ", fused)
+        vq.embedding.weight.grad = None
+        ml = ml0.clone().requires_grad_(True)
+        z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, 1234, True, vq)
+        loss = 1.3 * vq_loss + (z_q * r).sum() + 0.7 * kl
+        loss.backward()
+        outs.append((z.detach(), kl.detach(), vq_loss.detach(), z_q.detach(), idx, ml.grad.clone(), vq.embedding.weight.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # the column sums offered to the encoder head's bias gradient
+    monkeypatch.setenv("CEEG_FUSED_RVQ", "1")
+    ml = ml0.clone().requires_grad_(True)
+    z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, 1234, True, vq)
+    got = {}
+    def hook(g):
+        got["cs"] = _take_colsum(g)
+    ml.register_hook(hook)
+    (1.3 * vq_loss + (z_q * r).sum() + 0.7 * kl).backward()
+    assert got["cs"] is not None
+    ref = ml.grad.double().sum(0)
+    np.testing.assert_allclose(got["cs"].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()) + 1e-30)
