@@ -51,7 +51,7 @@ struct DcNode {  // one pipeline stage of dc_grad_rows_kernel: a node's three li
 
 template <int T>
 __device__ __forceinline__ int dc_bcast(int v) {  // lane T of the caller's 16-lane DPP row, in every lane of that row
-  return __builtin_amdgcn_update_dpp(0, v, 0x150 + T, 0xf, 0xf, false);
+  return __builtin_amdgcn_mov_dpp(v, 0x150 + T, 0xf, 0xf, false);  // every lane has a source: no `old` value to set up
 }
 template <int T>
 __device__ __forceinline__ float dc_bcastf(float v) { return __int_as_float(dc_bcast<T>(__float_as_int(v))); }
