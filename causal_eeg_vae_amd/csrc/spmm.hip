@@ -160,6 +160,24 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_kernel(
   }
 }
 
+// the same pieces from a list the caller built once per graph: item = (lo, hi, chunk*2 + slot, row); one wave per item,
+// no row search and no waves for the chunks that hold no long row (config 2's transposed graph: 3.4 k items in 66 k chunks)
+template <int LPR>
+__global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_items_kernel(
+    const int4* __restrict__ items, int64_t n_items, const int32_t* __restrict__ col, const float* __restrict__ val,
+    const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int F, int fbase, float* __restrict__ partial,
+    CeegSpmmEx ex) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + (threadIdx.x >> 6);
+  if (w >= n_items) return;
+  const int4 it = items[w];
+  const int fl = lane % LPR;
+  const int foff = fbase + 4 * fl;
+  const bool fl_ok = foff < F;
+  const float4 a = seg_sum<LPR>(col, val, vperm, X, ldx, it.x, it.y, lane, foff, fl_ok, ex);
+  if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + (size_t)it.z * (4 * LPR) + 4 * fl) = a;
+}
+
 // first row r in [0, N] with rowptr[r] >= target
 __device__ __forceinline__ int64_t row_lower_bound(const int32_t* __restrict__ rowptr, int64_t N, int64_t target) {
   int64_t lo = 0, hi = N;
@@ -301,7 +319,13 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
                 int64_t ldx, int64_t N, int64_t nnz, int F, int fbase, const float* bias, int relu, int accumulate,
                 float* out, int64_t ldo, float* partial, unsigned int* queue, hipStream_t st, const CeegSpmmEx& ex) {
   const int64_t nchunk = (nnz + SPMM_CHUNK - 1) / SPMM_CHUNK;
-  if (nchunk > 0 && !(ex.max_row_nnz >= 0 && ex.max_row_nnz <= SPMM_CHUNK)) {  // skipped when the caller knows there is no long row
+  if (nchunk > 0 && ex.long_items != nullptr) {  // the caller's piece list covers every row longer than SPMM_CHUNK
+    if (ex.n_long_items > 0) {
+      hipLaunchKernelGGL(spmm_long_items_kernel<LPR>, dim3((unsigned)((ex.n_long_items + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64),
+                         0, st, reinterpret_cast<const int4*>(ex.long_items), ex.n_long_items, col, val, vperm, X, ldx, F, fbase, partial, ex);
+      CEEG_CHECK_LAUNCH();
+    }
+  } else if (nchunk > 0 && !(ex.max_row_nnz >= 0 && ex.max_row_nnz <= SPMM_CHUNK)) {  // skipped when the caller knows there is no long row
     hipLaunchKernelGGL(spmm_long_kernel<LPR>, dim3((unsigned)((nchunk + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64), 0, st,
                        rowptr, col, val, vperm, X, ldx, N, F, fbase, partial, ex);
     CEEG_CHECK_LAUNCH();
@@ -366,6 +390,22 @@ extern "C" int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const fl
   CeegSpmmEx ex;
   ex.mod = N;
   ex.max_row_nnz = max_row_nnz;
+  return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream), ex);
+}
+
+extern "C" int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                                   const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                                   int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,
+                                   int64_t n_long, void* ws, size_t ws_bytes, void* stream) {
+  if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
+  if (max_row_nnz < 0 || (max_row_nnz > SPMM_CHUNK && n_long == 0)) return CEEG_EINVAL;  // long rows need their pieces listed
+  static const int32_t no_items[4] = {0, 0, 0, 0};
+  CeegSpmmEx ex;
+  ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
+  ex.long_items = n_long > 0 ? long_items : no_items;  // non-NULL: "the list is authoritative" (host pointer never read when empty)
+  ex.n_long_items = n_long;
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }

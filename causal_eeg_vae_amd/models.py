@@ -114,12 +114,14 @@ class EventGraph:
         # values in the transposed order, gathered once: the backward SpMM then streams them instead of chasing
         # val[t_perm[q]] (a dependent load in front of every row's gathers)
         self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
+        self.gcn.long_items(False), self.gcn.long_items(True)  # piece lists of the hub rows: graph-construction work
         self._dec = None
 
     @property
     def dec(self):
         if self._dec is None:
             self._dec = CsrPair(self.edge_index, self.num_nodes, self_loops=False)
+            self._dec.long_items(False), self._dec.long_items(True)
         return self._dec
 
 
@@ -129,13 +131,21 @@ def _as_graph(g, num_nodes):
     return EventGraph(g, num_nodes)
 
 
-def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1):
+def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1, items=False):
+    """items: False = let the kernel find the long rows; None / int32 [n,4] = the graph's piece list (CsrPair.long_items)."""
     L = _lib.lib()
     nnz = col.shape[0]
     F = x.shape[1]
     if out is None:
         out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
     ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
+    if items is not False and max_row >= 0:
+        with _lib.timed(f"spmm_F{F}"):
+            _lib.check(L.ceeg_spmm_csr_items(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
+                                             n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
+                                             int(max_row), _lib.ptr(items), 0 if items is None else items.shape[0], ws.data_ptr(), ws.numel(),
+                                             _lib.stream()), "ceeg_spmm_csr_items")
+        return out
     with _lib.timed(f"spmm_F{F}"):
         _lib.check(L.ceeg_spmm_csr(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
                                    n_rows, nnz, F, _lib.ptr(bias), int(relu), int(accumulate), out.data_ptr(), out.stride(0),
@@ -193,7 +203,7 @@ class _GcnAggregate(torch.autograd.Function):
         _lib.require_cuda(h)
         h = h.contiguous()
         g = graph.gcn
-        out = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, bias=bias, relu=relu, max_row=g.max_row)
+        out = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, bias=bias, relu=relu, max_row=g.max_row, items=g.long_items(False))
         ctx.graph, ctx.relu, ctx.has_bias = graph, bool(relu), bias is not None
         if relu:
             ctx.save_for_backward(out)
@@ -210,7 +220,7 @@ class _GcnAggregate(torch.autograd.Function):
             dbias = (_take_colsum(grad) if ctx.has_bias else None)
             if dbias is None and ctx.has_bias:
                 dbias = _colsum(grad)
-        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, grad, graph.num_nodes, max_row=g.max_trow) if ctx.needs_input_grad[0] else None
+        dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, grad, graph.num_nodes, max_row=g.max_trow, items=g.long_items(True)) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
 

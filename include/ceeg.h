@@ -122,6 +122,16 @@ int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, c
                   const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
                   int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream);
 
+/* ceeg_spmm_csr with the pieces of the long rows given as a list built once per graph (the graph is static across steps):
+ * long_items int32 [n_long][4] = (lo, hi, chunk*2 + slot, row) for every row longer than 256 entries, cut at the global
+ * positions k*256; slot = 1 for a piece that starts its row in the middle of a chunk, else 0 (the layout of
+ * ceeg_decoder_codes_*).  Same sums in the same order as ceeg_spmm_csr - bitwise equal - without the per-chunk row
+ * search: one wave per listed piece.  max_row_nnz must be the true longest row. */
+int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                        const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                        int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,
+                        int64_t n_long, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A3+A4  VGAE.reparametrize + VGAE.kl_loss (upstream PyG; anchors: MAX_LOGSTD scripts/run.py:13,
  *        BaseCVAE.reparameterize scripts/models.py:38-43), fused in one pass.

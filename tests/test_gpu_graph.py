@@ -167,3 +167,23 @@ def test_bias_relu_and_column_sums(N, F, ld):
     cs3 = _colsum(g)
     assert torch.equal(cs3, _colsum(g))
     assert float(((cs3.double() - g.double().sum(0)).abs() / (g.abs().double().sum(0) + 1e-30)).max()) < 1e-6
+
+
+def test_spmm_piece_list_equals_row_scan():
+    """ceeg_spmm_csr_items (hub-row pieces from the graph's static list) == ceeg_spmm_csr (per-chunk row search), bit for
+    bit, forward and transposed, with and without hub rows."""
+    from causal_eeg_vae_amd import EventGraph
+    from causal_eeg_vae_amd.models import _spmm
+    from causal_eeg_vae_amd.synth import synth_event_graph
+    for N, E in ((50_000, 800_000), (3_000, 20_000)):
+        g = EventGraph(synth_event_graph(N, E, seed=4, device="cuda"), N)
+        p = g.gcn
+        if N == 50_000:
+            assert p.max_trow > 256 and p.long_items(True) is not None
+        for F in (256, 128, 20):
+            x = torch.randn(N, F, device="cuda")
+            for rp, col, val, mr, tr in ((p.rowptr, p.col, g.gcn_val, p.max_row, False), (p.t_rowptr, p.t_col, g.gcn_tval, p.max_trow, True)):
+                a = _spmm(rp, col, val, None, x, N, max_row=mr)
+                b = _spmm(rp, col, val, None, x, N, max_row=mr, items=p.long_items(tr))
+                c = _spmm(rp, col, val, None, x, N)  # no hint at all
+                assert torch.equal(a, b) and torch.equal(a, c)
