@@ -112,15 +112,17 @@ __global__ __launch_bounds__(256) void dc_gram_kernel(const float* __restrict__ 
 // so the sums do not depend on scheduling.
 __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
-                                                           int64_t sig_a, int64_t sig_b, int64_t sig_mod, uint4* __restrict__ rec,
-                                                           float* __restrict__ part) {
+                                                           int64_t sig_a, int64_t sig_b, int64_t sig_mod, const float* __restrict__ row_add,
+                                                           uint4* __restrict__ rec, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t row0 = w * 64;
   if (row0 >= N) return;
   const int64_t r = row0 + lane;
   int lo = 0, hi = 0, sr = 0, slo = 0, shi = 0, kr = 0, ksr = 0;
+  float radd = 0.f;
   if (r < N) {
+    if (row_add) radd = row_add[r];
     lo = rowptr[r];
     hi = rowptr[r + 1];
     sr = (int)ceeg_block_affine(r, sig_a, sig_b, sig_mod);
@@ -137,6 +139,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
     const int p_lo = __shfl(lo, j, 64), p_hi = __shfl(hi, j, 64);
     const int g_sr = __shfl(sr, j, 64), g_slo = __shfl(slo, j, 64), g_shi = __shfl(shi, j, 64);
     const int g_kr = __shfl(kr, j, 64), g_ksr = __shfl(ksr, j, 64);
+    const float g_add = __shfl(radd, j, 64);
     const int s_n = g_shi - g_slo;
     const bool s_short = s_n <= 16;
     int sc = -1;  // sigma-row's columns across the group's lanes (never equal to a column id when absent)
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
       if (live && !s_short) hit = dc_sorted_has(col, g_slo, g_shi, c);
       if (live) {
         float tp, cp, tn, cn;
-        dc_terms(gr[kc], gs[kc], tp, cp, tn, cn);
+        dc_terms(gr[kc] + g_add, gs[kc] + g_add, tp, cp, tn, cn);
         const bool valid = c != g_sr && !hit;
         if (!valid) { tn = 0.f; cn = 0.f; }
         rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)g_kr | ((unsigned)g_ksr << 16), (unsigned)kc);
@@ -179,7 +182,8 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
 __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int4* __restrict__ items, int64_t n_items, int64_t sig_a, int64_t sig_b,
-                                                           int64_t sig_mod, uint4* __restrict__ rec, float* __restrict__ part, int64_t slot0) {
+                                                           int64_t sig_mod, const float* __restrict__ row_add, uint4* __restrict__ rec,
+                                                           float* __restrict__ part, int64_t slot0) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_items) return;
@@ -190,6 +194,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
   const int kr = dc_clamp_code(code[r], K), ksr = dc_clamp_code(code[sr], K);
   const float* gr = G + (size_t)kr * K;
   const float* gs = G + (size_t)ksr * K;
+  const float radd = row_add ? row_add[r] : 0.f;
   float a_pos = 0.f, a_neg = 0.f, a_cnt = 0.f;
   for (int base = lo; base < hi; base += 64) {
     const int p = base + lane;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
       const int c = col[p];
       const int kc = dc_clamp_code(code[c], K);
       float tp, cp, tn, cn;
-      dc_terms(gr[kc], gs[kc], tp, cp, tn, cn);
+      dc_terms(gr[kc] + radd, gs[kc] + radd, tp, cp, tn, cn);
       const bool valid = c != sr && !dc_sorted_has(col, slo, shi, c);
       if (!valid) { tn = 0.f; cn = 0.f; }
       rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)kr | ((unsigned)ksr << 16), (unsigned)kc);
@@ -439,6 +444,45 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_long_kernel(DcGradArg
   }
 }
 
+// S[n] = gp * (sum_{p in row n} cp + sum_{q in trow n} cp[tperm q]) + gn * (sum_{p in row sigma^-1 n} cn + sum_{q in trow n} cn[tperm q]):
+// the factor of every input column that is CONSTANT over the pairs of a node (a per-graph condition appended to the latent).
+// Wave w owns nodes [64 w, 64 w + 64), a 16-lane group per node; lane l adds entries l, l+16, ... in order, then a fixed butterfly.
+__global__ __launch_bounds__(256) void dc_coef_sum_kernel(DcGradArgs a, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n0 = w * 64;
+  if (n0 >= a.N) return;
+  const float gp = a.gscale[0], gn = a.gscale[1];
+  const int64_t n = n0 + lane;
+  int alo = 0, ahi = 0, blo = 0, bhi = 0, clo = 0, chi = 0;
+  if (n < a.N) {
+    alo = a.rowptr[n]; ahi = a.rowptr[n + 1];
+    const int64_t m = dc_sigma_inv(n, a.sig_ainv, a.sig_b, a.sig_mod);
+    blo = a.rowptr[m]; bhi = a.rowptr[m + 1];
+    clo = a.t_rowptr[n]; chi = a.t_rowptr[n + 1];
+  }
+  const int cnt = a.N - n0 < 64 ? (int)(a.N - n0) : 64;
+  for (int it = 0; it * 4 < cnt; ++it) {
+    const int j = it * 4 + grp;
+    const int A_lo = __shfl(alo, j, 64), A_hi = __shfl(ahi, j, 64), B_lo = __shfl(blo, j, 64), B_hi = __shfl(bhi, j, 64);
+    const int C_lo = __shfl(clo, j, 64), C_hi = __shfl(chi, j, 64);
+    float sp = 0.f, sn = 0.f;
+    for (int p = A_lo + gl; p < A_hi; p += 16) sp += __uint_as_float(a.rec[p].x);
+    for (int p = B_lo + gl; p < B_hi; p += 16) sn += __uint_as_float(a.rec[p].y);
+    for (int q = C_lo + gl; q < C_hi; q += 16) {
+      const uint4 r = a.rec[a.t_perm[q]];
+      sp += __uint_as_float(r.x);
+      sn += __uint_as_float(r.y);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      sp += __shfl_xor(sp, o, 64);
+      sn += __shfl_xor(sn, o, 64);
+    }
+    if (gl == 0 && j < cnt) out[n0 + j] = gp * sp + gn * sn;
+  }
+}
+
 bool dc_supported(int n_e, int D) { return n_e >= 1 && n_e <= DC_MAX_K && D >= DC_CW && D <= 256 && (D % DC_CW) == 0; }
 size_t dc_part_bytes(int64_t nnz, int D, int64_t n_items) {
   if (n_items <= 0) return 0;
@@ -460,8 +504,8 @@ extern "C" size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, i
 
 extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
                                       const int32_t* col, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
-                                      const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, void* rec, float* sums,
-                                      void* ws, size_t ws_bytes, void* stream) {
+                                      const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, const float* row_add, void* rec,
+                                      float* sums, void* ws, size_t ws_bytes, void* stream) {
   if (!W || !code || !rowptr || !sums || N <= 0 || nnz < 0 || (nnz > 0 && (!col || !rec))) return CEEG_EINVAL;
   if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (rec && !ceeg_aligned(rec, 16))) return CEEG_EINVAL;
@@ -478,11 +522,11 @@ extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int 
   CEEG_CHECK_LAUNCH();
   uint4* r4 = static_cast<uint4*>(rec);
   hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col, N, sig_a, sig_b,
-                     sig_mod, r4, part);
+                     sig_mod, row_add, r4, part);
   CEEG_CHECK_LAUNCH();
   if (n_long > 0) {
     hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col,
-                       reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, r4, part, nwave);
+                       reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, row_add, r4, part, nwave);
     CEEG_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nslot, sums);
@@ -494,7 +538,7 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
                                       const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
                                       int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
                                       int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
-                                      float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream) {
+                                      float* dz, int64_t lddz, float* coef_sum, void* ws, size_t ws_bytes, void* stream) {
   if (!W || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0 || (nnz > 0 && (!t_perm || !rec))) return CEEG_EINVAL;
   if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) || (rec && !ceeg_aligned(rec, 16)))
@@ -538,5 +582,9 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
   }
   hipLaunchKernelGGL(dc_grad_rows_kernel, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
   CEEG_CHECK_LAUNCH();
+  if (coef_sum) {
+    hipLaunchKernelGGL(dc_coef_sum_kernel, dim3((unsigned)(((N + 63) / 64 + 3) / 4)), dim3(256), 0, st, a, coef_sum);
+    CEEG_CHECK_LAUNCH();
+  }
   return CEEG_OK;
 }

@@ -545,7 +545,7 @@ class _FusedDecoder(torch.autograd.Function):
     """recon_loss with permutation-structured negatives: one gather pass for both terms (ceeg_decoder_fused_*)."""
 
     @staticmethod
-    def forward(ctx, z, graph, a, b, ainv, row_sums=True, sig_mod=None, table=None, table_idx=None):
+    def forward(ctx, z, graph, a, b, ainv, row_sums=True, sig_mod=None, table=None, table_idx=None, cond_rows=None):
         """table / table_idx: a quantised latent given as (codebook [n_e, D], int32 code per node) with
         z[n] == table[table_idx[n]] bit for bit (what VectorQuantizer's forward returns in fp32): the kernels then
         gather codebook rows through the 4-byte index instead of D*4-byte rows of z.  Gradients still flow to z."""
@@ -553,6 +553,17 @@ class _FusedDecoder(torch.autograd.Function):
         L = _lib.lib()
         N, D = z.shape
         mod = int(N if sig_mod is None else sig_mod)
+        # cond_rows [N, C]: extra decoder-input columns that are constant over every pair of a node (a per-graph condition,
+        # block-diagonal batch, sigma inside the graphs): the code form folds them into a per-row addend; any other form
+        # decodes the concatenation cat((z, cond_rows)) (scripts/models.py:259)
+        ctx.cond_split = None
+        use_codes = (table is not None and os.environ.get("CEEG_DEC_CODES", "1") == "1"
+                     and L.ceeg_decoder_codes_supported(int(table.shape[0]), D) == 1)
+        if cond_rows is not None and not use_codes:
+            ctx.cond_split = (D, cond_rows.shape[1])
+            z = torch.cat((z, cond_rows), dim=1)
+            N, D = z.shape
+            table = table_idx = None
         if table is not None:
             src, sidx = table.detach().contiguous(), table_idx.contiguous()
             if src.shape[1] != D or sidx.shape[0] != N or sidx.dtype != torch.int32:
@@ -562,19 +573,23 @@ class _FusedDecoder(torch.autograd.Function):
         z = src
         p = graph.dec
         sums = torch.empty(3, dtype=torch.float32, device=z.device)
-        ctx.codes = (table is not None and os.environ.get("CEEG_DEC_CODES", "1") == "1"
-                     and L.ceeg_decoder_codes_supported(int(src.shape[0]), D) == 1)
+        ctx.codes = use_codes and table is not None
+        ctx.cond = None
         if ctx.codes:
             # code form: dots from the Gram matrix of the codebook, gradient from an LDS-resident codebook slab
             li, lt = p.long_items(False), p.long_items(True)
             ctx.items = (li, lt)
             rec = torch.empty(max(p.nnz, 1), 4, dtype=torch.int32, device=z.device)
+            row_add = None
+            if cond_rows is not None:
+                ctx.cond = cond_rows.detach().contiguous()
+                row_add = (ctx.cond * ctx.cond).sum(dim=1).contiguous()  # |c_graph(r)|^2: the condition's share of every dot of row r
             ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, src.shape[0], D, 0 if li is None else li.shape[0], 0), z.device)
             with _lib.timed("decoder_fwd"):
                 _lib.check(L.ceeg_decoder_codes_fwd(src.data_ptr(), src.stride(0), src.shape[0], D, sidx.data_ptr(), p.rowptr.data_ptr(),
                                                     p.col.data_ptr(), N, p.nnz, a, b, mod, _lib.ptr(li), 0 if li is None else li.shape[0],
-                                                    p.max_row, rec.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
-                           "ceeg_decoder_codes_fwd")
+                                                    p.max_row, _lib.ptr(row_add), rec.data_ptr(), sums.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                    _lib.stream()), "ceeg_decoder_codes_fwd")
             coef = rec
             ctx.grow = None
         else:
@@ -609,12 +624,14 @@ class _FusedDecoder(torch.autograd.Function):
             li, lt = ctx.items
             nl, nt = (0 if li is None else li.shape[0]), (0 if lt is None else lt.shape[0])
             ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, z.shape[0], D, nl, nt), z.device)
+            csum = torch.empty(N, dtype=torch.float32, device=z.device) if ctx.cond is not None else None
             with _lib.timed("decoder_bwd"):
                 _lib.check(L.ceeg_decoder_codes_bwd(z.data_ptr(), z.stride(0), z.shape[0], D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(),
                                                     p.t_perm.data_ptr(), N, p.nnz, a, b, ainv, mod, _lib.ptr(li), nl, _lib.ptr(lt), nt,
                                                     p.max_row, p.max_trow, coef.data_ptr(), gscale.data_ptr(), dz.data_ptr(), dz.stride(0),
-                                                    ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_codes_bwd")
-            return dz, None, None, None, None, None, None, None, None
+                                                    _lib.ptr(csum), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_codes_bwd")
+            dcond = None if csum is None else csum[:, None] * ctx.cond
+            return dz, None, None, None, None, None, None, None, None, dcond
         cp, cn = coef[:, 0], coef[:, 1]
         ws = _lib.workspace(L.ceeg_decoder_fused_ws_bytes(N, p.nnz, D), z.device)
         grow = ctx.grow
@@ -625,7 +642,10 @@ class _FusedDecoder(torch.autograd.Function):
                                                 gscale.data_ptr(), dz.data_ptr(), dz.stride(0), p.max_row, p.max_trow, ws.data_ptr(), ws.numel(),
                                                 _lib.stream()), "ceeg_decoder_fused_bwd")
         ctx.grow = None
-        return dz, None, None, None, None, None, None, None, None
+        if ctx.cond_split is not None:
+            d0, c0 = ctx.cond_split
+            return dz[:, :d0], None, None, None, None, None, None, None, None, dz[:, d0:]
+        return dz, None, None, None, None, None, None, None, None, None
 
 
 # ==================================================================================================
@@ -744,6 +764,21 @@ class ConditionalVGAEVQ(nn.Module):
         self.vector_quantization = VectorQuantizer(num_latent_embeddings, latent, beta, return_one_hot=False)
         self.latent, self.cond_channels, self.seed = latent, cond_channels, int(seed)
 
+    @staticmethod
+    def _intra_graph(graph, batch, mod):
+        """True when `batch` is the block layout of equal-sized graphs (node n in graph n // mod) and no edge crosses
+        graphs - checked once per graph object (graph-construction work, one host sync)."""
+        key = (batch.data_ptr(), int(mod))
+        cache = getattr(graph, "_intra", None)
+        if cache is None or cache[0] != key:
+            n = batch.shape[0]
+            blocks = torch.arange(n, device=batch.device) // int(mod)
+            ei = graph.edge_index
+            ok = bool(torch.equal(batch.to(torch.int64), blocks)) and bool((blocks[ei[0]] == blocks[ei[1]]).all())
+            graph._intra = (key, ok)
+            cache = graph._intra
+        return cache[1]
+
     def forward(self, x, graph, batch, condition, step=0, eps=None, sigma=None, nodes_per_graph=None):
         N = x.shape[0]
         if batch.shape[0] != N or condition.shape[1] != self.cond_channels:
@@ -756,7 +791,13 @@ class ConditionalVGAEVQ(nn.Module):
         if N % mod:
             raise ValueError("nodes_per_graph must divide the number of nodes of the batch")
         a, b, ainv = sigma_params(mod, self.seed, step) if sigma is None else sigma
-        rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
+        if nodes_per_graph is not None and self._intra_graph(graph, batch, mod):
+            # every positive and negative pair joins two nodes of ONE graph: the condition's share of a dot product is
+            # |c_graph|^2, so the decoder runs in code form on z_q with cn as constant extra columns
+            rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, mod, self.vector_quantization.embedding.weight,
+                                            idx.view(-1).to(torch.int32), cn)
+        else:
+            rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
         loss = rec + kl / N + vq_loss
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
 

@@ -238,19 +238,23 @@ int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, con
  * k*256; the caller passes them as piece lists built once per graph: long_items / t_long_items, int32 [n][4] =
  * (lo, hi, chunk*2 + slot, row) with slot = 1 for a piece that starts its row in the middle of a chunk, else 0
  * (CSR rows resp. transposed rows; required when max_row_nnz / max_trow_nnz > 256, else NULL / 0).
+ * Conditional decoders (scripts/models.py:259 `cat((latent, condition))` with a condition that is constant inside a graph,
+ * block-diagonal batch, sig_mod = nodes per graph): the condition's share of every dot product of row r is the constant
+ * |c_graph(r)|^2 - pass it as row_add[r] (float [N], NULL = 0); the backward's coef_sum[n] (float [N], NULL = not wanted)
+ * is the summed, scaled coefficient of all pairs of node n, so d loss / d condition_columns[n] = coef_sum[n] * c_graph(n).
  * No counterpart in the reference beyond A6 itself; an algebraic re-association for the quantised case. */
 int ceeg_decoder_codes_chunk(void);
 int ceeg_decoder_codes_supported(int n_e, int D);
 size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);
 int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
                            const int32_t* col, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_mod,
-                           const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, void* rec, float* sums,
-                           void* ws, size_t ws_bytes, void* stream);
+                           const int32_t* long_items, int64_t n_long, int64_t max_row_nnz, const float* row_add, void* rec,
+                           float* sums, void* ws, size_t ws_bytes, void* stream);
 int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
                            const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
                            int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
                            int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
-                           float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+                           float* dz, int64_t lddz, float* coef_sum, void* ws, size_t ws_bytes, void* stream);
 
 /* Streaming helpers around the dense transform of a GCN layer (no counterpart of their own in the reference:
  * they stand where its host code calls torch.relu / autograd's ReLU backward / the bias-gradient reduction).

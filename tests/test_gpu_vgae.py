@@ -174,14 +174,14 @@ def test_full_step_vs_oracle():
             _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
 
 
-@pytest.mark.parametrize("per_graph", [True, False])
-def test_conditional_batched_step_vs_oracle(per_graph):
+@pytest.mark.parametrize("per_graph,D,n_e", [(True, 12, 32), (False, 12, 32), (True, 64, 100), (False, 64, 100)])
+def test_conditional_batched_step_vs_oracle(per_graph, D, n_e):
     """Config 4's form: 8 collated graphs, per-graph condition c[batch] concatenated to the encoder
     input and to the latent before decoding; negatives inside each graph (block permutation) or over the whole batch."""
     from causal_eeg_vae_amd import ConditionalVGAEVQ, EventGraph, sigma_params
     from causal_eeg_vae_amd.synth import collate_graphs
     from oracle import ref_torch
-    G, n, e, Fi, C, D, n_e = 8, 500, 6000, 28, 4, 12, 32
+    G, n, e, Fi, C = 8, 500, 6000, 28, 4   # D = 64 with per-graph negatives: the code-form decoder with the condition as a row addend
     eis = [torch.from_numpy(_graph(n, e, 10 + g)) for g in range(G)]
     ei, batch, N = collate_graphs(eis, [n] * G)
     assert N == G * n and int(batch[-1]) == G - 1
@@ -559,3 +559,45 @@ def test_fused_reparam_vq_backward_equals_the_two_steps(N, D, n_e, with_eps, mon
     assert got["cs"] is not None
     ref = ml.grad.double().sum(0)
     np.testing.assert_allclose(got["cs"].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()) + 1e-30)
+
+
+def test_decoder_code_form_with_condition_columns():
+    """cat((z_q, c[batch])) decoded (a) in code form with |c_graph|^2 as the row addend and coef_sum * c as the condition's
+    gradient, (b) as the concatenated matrix through the row-gather kernels: same loss, count, gradients."""
+    from causal_eeg_vae_amd import EventGraph, sigma_params
+    from causal_eeg_vae_amd.models import _FusedDecoder
+    import os
+    n, G, D, C, n_e = 400, 5, 128, 8, 512
+    eis = [_graph(n, 5000, 200 + g) + g * n for g in range(G)]
+    ei_np = np.concatenate(eis, axis=1)
+    N = n * G
+    g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    a_, b_, ainv = sigma_params(n, 7, 1)
+    torch.manual_seed(0)
+    W = (torch.randn(n_e, D) * (1.5 / D ** 0.5)).cuda()
+    idx = torch.randint(0, n_e, (N,), dtype=torch.int32).cuda()
+    cond = (torch.randn(G, C) * 0.5).cuda()
+    batch = torch.arange(N, device="cuda") // n
+    outs = []
+    for env in ("1", "0"):
+        os.environ["CEEG_DEC_CODES"] = env
+        try:
+            zq = W[idx.long()].clone().requires_grad_(True)
+            c = cond.clone().requires_grad_(True)
+            cn = c.index_select(0, batch)
+            rec, sums = _FusedDecoder.apply(zq, g, a_, b_, ainv, True, n, W, idx, cn)
+            (rec * 1.3).backward()
+            outs.append((rec.detach(), sums.clone(), zq.grad.clone(), c.grad.clone()))
+        finally:
+            os.environ.pop("CEEG_DEC_CODES", None)
+    (r1, s1, gz1, gc1), (r0, s0, gz0, gc0) = outs
+    assert float(s1[2]) == float(s0[2])
+    _close(r1, r0, rtol=1e-5)
+    _close(gz1, gz0, rtol=1e-4, atol_rel=1e-5)
+    _close(gc1, gc0, rtol=1e-4, atol_rel=1e-5)
+    # the plain concatenation (no table at all) agrees too
+    zc = torch.cat((W[idx.long()], cond.index_select(0, batch)), dim=1).clone().requires_grad_(True)
+    r2, s2 = _FusedDecoder.apply(zc, g, a_, b_, ainv, True, n)
+    (r2 * 1.3).backward()
+    _close(r1, r2, rtol=1e-5)
+    _close(gz1, zc.grad[:, :D], rtol=1e-4, atol_rel=1e-5)
