@@ -69,28 +69,34 @@ class CsrPair:
         return self.rowptr.device
 
     def long_items(self, transposed=False):
-        """Piece list of the rows longer than ceeg_decoder_codes_chunk() entries (include/ceeg.h, ceeg_decoder_codes_*):
-        int32 [n][4] = (lo, hi, chunk*2 + slot, row), rows ascending, pieces ascending; None when no row is that long.
-        Static per graph: built once (graph-construction work, one host sync), never inside a step."""
+        """Piece list of the rows longer than ceeg_decoder_codes_chunk() entries (include/ceeg.h, ceeg_decoder_codes_* and
+        ceeg_spmm_csr_items); None when no row is that long.  Static per graph: built once (graph-construction work, one
+        host sync), never inside a step."""
         key = bool(transposed)
         if key not in self._long:
             chunk = int(_lib.lib().ceeg_decoder_codes_chunk())
-            rp = (self.t_rowptr if transposed else self.rowptr).long()
-            rows = torch.nonzero((rp[1:] - rp[:-1]) > chunk).view(-1)
-            if rows.numel() == 0:
-                self._long[key] = None
-            else:
-                lo_r, hi_r = rp[rows], rp[rows + 1]
-                c_lo, c_hi = lo_r // chunk, (hi_r - 1) // chunk
-                cnt = c_hi - c_lo + 1
-                rid = torch.repeat_interleave(torch.arange(rows.numel(), device=rp.device), cnt)
-                first = torch.cumsum(cnt, 0) - cnt
-                c = c_lo[rid] + (torch.arange(rid.numel(), device=rp.device) - first[rid])
-                lo = torch.maximum(lo_r[rid], c * chunk)
-                hi = torch.minimum(hi_r[rid], (c + 1) * chunk)
-                slot = ((c == c_lo[rid]) & (lo_r[rid] != c * chunk)).long()
-                self._long[key] = torch.stack([lo, hi, c * 2 + slot, rows[rid]], dim=1).to(torch.int32).contiguous()
+            self._long[key] = build_long_items(self.t_rowptr if transposed else self.rowptr, chunk)
         return self._long[key]
+
+
+def build_long_items(rowptr, chunk):
+    """int32 [n][4] = (lo, hi, chunk_index*2 + slot, row): every row longer than `chunk` entries cut at the GLOBAL positions
+    k*chunk, rows ascending, pieces ascending; slot = 1 for the piece that starts its row in the middle of a chunk (a chunk
+    can hold the tail of one long row and the head of the next), else 0.  None when no row is that long."""
+    rp = rowptr.long()
+    rows = torch.nonzero((rp[1:] - rp[:-1]) > chunk).view(-1)
+    if rows.numel() == 0:
+        return None
+    lo_r, hi_r = rp[rows], rp[rows + 1]
+    c_lo, c_hi = lo_r // chunk, (hi_r - 1) // chunk
+    cnt = c_hi - c_lo + 1
+    rid = torch.repeat_interleave(torch.arange(rows.numel(), device=rp.device), cnt)
+    first = torch.cumsum(cnt, 0) - cnt
+    c = c_lo[rid] + (torch.arange(rid.numel(), device=rp.device) - first[rid])
+    lo = torch.maximum(lo_r[rid], c * chunk)
+    hi = torch.minimum(hi_r[rid], (c + 1) * chunk)
+    slot = ((c == c_lo[rid]) & (lo_r[rid] != c * chunk)).long()
+    return torch.stack([lo, hi, c * 2 + slot, rows[rid]], dim=1).to(torch.int32).contiguous()
 
 
 class EventGraph:
