@@ -17,6 +17,7 @@
 //          C is seeded with -ee/2 so the accumulator IS the score (no epilogue arithmetic).
 // The codebook is streamed through LDS in chunks of CT codes; z tiles live in registers for the whole
 // kernel (each z element is read from HBM exactly once).
+#include <stdlib.h>
 #include "ceeg_internal.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -520,6 +521,302 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
   if (threadIdx.x == 0) err_part[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------------------------------ bf16 main, codebook-stationary
+// D == DP, n_ep == 128 * NCT (NCT in {1, 2, 4}): the WHOLE codebook lives in the registers of one 512-thread workgroup for
+// the lifetime of a persistent kernel - wave w holds codes [16 NCT w, 16 NCT (w+1)) as MFMA B operands (NCT * DP/8 VGPRs)
+// - and the latent rows stream through LDS in double-buffered 64-row tiles (LDS-DMA, XOR-swizzled pieces).  Against
+// vq_main_bf16 (rows stationary, codebook re-staged through LDS for every 256 rows):
+//   * no codebook traffic after the first microseconds, no chunk barriers;
+//   * the streamed operand is the SMALL one per MFMA batch (A: 4 VGPRs per k-step, double-buffered by the compiler,
+//     where the row-stationary kernel at 256 VGPRs waits on every single-buffered ds_read_b128);
+//   * per 16-row tile a wave reduces its NCT*16 codes across the 16 code lanes with DPP row rotations (v_max / v_min with
+//     a DPP operand: 10 VALU per row value), the 8 waves' candidates meet in LDS, lowest code wins ties (strict > in
+//     ascending wave order = ascending code order);
+//   * squared error of a row = |z|^2 - 2 * best score (the accumulator, seeded with -|w|^2/2, IS z.w - |w|^2/2 for the
+//     bf16-rounded row that z_q returns); z_q rows are copied from the bf16 image.
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+constexpr int VQ_BS_WAVES = 8;
+constexpr int VQ_BS_TR = 64;  // rows per LDS tile
+
+template <int CTRL>
+__device__ __forceinline__ float vq_dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false)); }
+template <int CTRL>
+__device__ __forceinline__ int vq_dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, false); }
+
+// max without fmaxf's NaN canonicalisation of each operand (v_med3_f32 with +inf: one VALU op)
+__device__ __forceinline__ float vq_max(float a, float b) { return __builtin_amdgcn_fmed3f(a, b, INFINITY); }
+// combine a value over the wave's four 16-lane rows (lanes r, r+16, r+32, r+48), one xor step per call, with gfx950's
+// v_permlane16_swap / v_permlane32_swap (VALU, no LDS round trip): after the swap the two results hold both partners.
+template <int STEP>
+__device__ __forceinline__ float vq_xrow_max(float v) {
+  const unsigned u = __float_as_uint(v);
+  const auto p = STEP == 16 ? __builtin_amdgcn_permlane16_swap(u, u, false, false) : __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return vq_max(__uint_as_float(p[0]), __uint_as_float(p[1]));
+}
+template <int STEP>
+__device__ __forceinline__ int vq_xrow_min(int v) {
+  const auto p = STEP == 16 ? __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false)
+                            : __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+  return min((int)p[0], (int)p[1]);
+}
+
+// Scores of one 64-row LDS tile against this wave's codes; per row the wave's best (score, lowest code) -> red_s / red_c.
+// The LDS tile arrives as a __restrict__ parameter on purpose: after inlining its reads carry alias-scope metadata, which
+// keeps the compiler from putting a conservative "wait for every outstanding LDS-DMA" in front of them (the DMA that is
+// in flight writes the OTHER buffer; the kernel waits for it explicitly before the barrier that publishes it).
+// The codebook is the MFMA's A operand, so lane (r, q) ends up with ONE latent row (r) and 4 NCT codes (16 ct + 4 q + i):
+// the row maximum is a per-lane chain, then two cross-row steps (lanes r, r+16, r+32, r+48); the winner's code is the
+// lowest one whose score equals the maximum.  Returns |z_row|^2 of row tid / 8 (all 8 threads of the row hold it).
+template <int DP, int NCT, int IL>
+__device__ __forceinline__ float vq_bs_tile(const char* __restrict__ zb, const u16x8 (&b)[NCT][DP / 32], const f32x4 (&bias)[NCT],
+                                            float* __restrict__ red_s, int* __restrict__ red_c) {
+  constexpr int KS = DP / 32;
+  constexpr int CPR = DP / 8;
+  constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
+  constexpr int TR = VQ_BS_TR;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  // |z_row|^2: 8 threads per row, v_dot2_f32_bf16 over their pieces (any order: the swizzle does not matter), xor butterfly
+  float zz = 0.f;
+  {
+    const int row = tid >> 3, part = tid & 7;
+#pragma unroll
+    for (int pp = 0; pp < (CPR + 7) / 8; ++pp) {
+      const int pos = part + 8 * pp;
+      if (CPR % 8 == 0 || pos < CPR) {
+        const uint4 u = *reinterpret_cast<const uint4*>(zb + (size_t)row * DP * 2 + (size_t)pos * 16);
+        zz = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, u.x), __builtin_bit_cast(bf16x2_t, u.x), zz, false);
+        zz = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, u.y), __builtin_bit_cast(bf16x2_t, u.y), zz, false);
+        zz = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, u.z), __builtin_bit_cast(bf16x2_t, u.z), zz, false);
+        zz = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, u.w), __builtin_bit_cast(bf16x2_t, u.w), zz, false);
+      }
+    }
+    zz += vq_dpp_f<0xB1>(zz);   // quad_perm [1,0,3,2]
+    zz += vq_dpp_f<0x4E>(zz);   // quad_perm [2,3,0,1]
+    zz += vq_dpp_f<0x141>(zz);  // row_half_mirror: lane l <- lane 7 - l inside each 8 (the other quad's total)
+  }
+
+  // operand addresses: row rt * 16 + r has the same swizzle for every rt (16 | SWZ_MASK + 1), and the swizzle only touches
+  // the low bits of the piece index, so a lane needs min(KS, 4) addresses per tile; the rest are immediate offsets
+  int* wdst = ((q & 1) ? red_c : reinterpret_cast<int*>(red_s)) + wave * TR + r;
+  constexpr int NA = KS < 4 ? KS : 4;
+  const char* pa[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) pa[j] = zb + (size_t)r * DP * 2 + ((((4 * j + q) & SWZ_MASK) ^ (r & SWZ_MASK)) << 4) + (((4 * j + q) & ~SWZ_MASK) << 4);
+  auto scores = [&](int rt, f32x4 (&acc)[NCT]) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const u16x8 a = *reinterpret_cast<const u16x8*>(pa[s % NA] + rt * 16 * DP * 2 + (s / NA) * NA * 64);
+#pragma unroll
+      for (int ct = 0; ct < NCT; ++ct)
+        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[ct][s]), __builtin_bit_cast(bf16x8_t, a),
+                                                         s == 0 ? bias[ct] : acc[ct], 0, 0, 0);
+    }
+  };
+  auto winner = [&](int rt, const f32x4 (&acc)[NCT]) {
+    float m = acc[0][0];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+      for (int i = (ct == 0 ? 1 : 0); i < 4; ++i) m = vq_max(m, acc[ct][i]);
+    m = vq_xrow_max<16>(m);
+    m = vq_xrow_max<32>(m);
+    int cand = 1 << 20;  // "not mine"
+#pragma unroll
+    for (int ct = NCT - 1; ct >= 0; --ct)
+#pragma unroll
+      for (int i = 3; i >= 0; --i) cand = (acc[ct][i] == m) ? ct * 16 + i : cand;
+    cand += wave * 16 * NCT + 4 * q;
+    cand = vq_xrow_min<16>(cand);
+    cand = vq_xrow_min<32>(cand);
+    // all four lanes of a row hold (m, cand): even q stores the score, odd q the code - one branch-free LDS store, so the
+    // four row tiles stay one basic block and their MFMAs and epilogues can be interleaved
+    wdst[rt * 16] = (q & 1) ? cand : __float_as_int(m);
+  };
+  if constexpr (IL) {
+    // software pipeline: the MFMAs of row tile rt are issued between the VALU of row tile rt - 1's winner search
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2][NCT];
+    scores(0, acc[0]);
+#pragma unroll
+    for (int rt = 1; rt < TR / 16; ++rt) {
+      scores(rt, acc[rt & 1]);
+      winner(rt - 1, acc[(rt - 1) & 1]);
+    }
+    winner(TR / 16 - 1, acc[(TR / 16 - 1) & 1]);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {  // prologue: reads + MFMAs of row tile 0
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
+    }
+#pragma unroll
+    for (int rt = 1; rt < TR / 16; ++rt)
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, IL, 0);
+        }
+      }
+  } else {
+#pragma unroll
+    for (int rt = 0; rt < TR / 16; ++rt) {
+      f32x4 acc[NCT];
+      scores(rt, acc);
+      winner(rt, acc);
+    }
+  }
+  return zz;
+}
+
+template <int DP, int NCT, int IL>
+__global__ __launch_bounds__(VQ_BS_WAVES * 64, 1) void vq_main_bf16_bs(
+    const unsigned short* __restrict__ z, const unsigned short* __restrict__ img, int64_t B,
+    unsigned short* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
+  constexpr int KS = DP / 32;
+  constexpr int CPR = DP / 8;                       // 16-byte pieces per row
+  constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
+  constexpr int CT = 64;                            // codes per image chunk (vq_prep_kernel's layout)
+  constexpr int CHB = CT * DP * 2 + CT * 4;
+  constexpr int TR = VQ_BS_TR;
+  constexpr int TILE_BYTES = TR * DP * 2;
+  constexpr int THREADS = VQ_BS_WAVES * 64;
+  constexpr int PIECES = TR * CPR;                  // 16-byte pieces per tile
+  constexpr int RED = VQ_BS_WAVES * TR;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* zbuf = smem;                                                   // [2][TILE_BYTES]
+  float* red_s = reinterpret_cast<float*>(smem + 2 * TILE_BYTES);      // [2][WAVES][TR]
+  int* red_c = reinterpret_cast<int*>(red_s + 2 * RED);                // [2][WAVES][TR]
+  float* lds_red = reinterpret_cast<float*>(red_c + 2 * RED);          // [WAVES]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const char* gimg = reinterpret_cast<const char*>(img);
+
+  // ---- this wave's codes -> registers (MFMA A operands) + their -|w|^2/2 as the accumulators' initial value
+  u16x8 b[NCT][KS];
+  f32x4 bias[NCT];  // accumulator rows 4q..4q+3 of tile ct = codes 16 ct + 4 q + i
+#pragma unroll
+  for (int ct = 0; ct < NCT; ++ct) {
+    const int c = wave * 16 * NCT + ct * 16 + r;
+    const char* row = gimg + (size_t)(c / CT) * CHB + (size_t)(c % CT) * DP * 2;
+    const int sw = c & SWZ_MASK;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) b[ct][s] = *reinterpret_cast<const u16x8*>(row + (((4 * s + q) ^ sw) << 4));
+    const int c4 = wave * 16 * NCT + ct * 16 + 4 * q;
+    bias[ct] = *reinterpret_cast<const f32x4*>(gimg + (size_t)(c4 / CT) * CHB + (size_t)CT * DP * 2 + (size_t)(c4 % CT) * 4);
+  }
+
+  const int64_t ntiles = (B + TR - 1) / TR;
+  // LDS slot L of a tile (16 bytes each) holds piece (L % CPR) ^ (row & SWZ_MASK) of row L / CPR: conflict-free operand reads
+  auto stage = [&](int64_t tile, int buf) {
+    const bool full = (tile + 1) * TR <= B;  // uniform: no per-row clamp on the common path
+#pragma unroll
+    for (int j0 = 0; j0 < PIECES; j0 += THREADS) {
+      const int L = j0 + tid;
+      if (PIECES % THREADS == 0 || L < PIECES) {
+        const int row = L / CPR, pos = L % CPR;
+        const int p = pos ^ (row & SWZ_MASK);
+        const unsigned short* src;
+        if (full) {
+          src = z + tile * (TR * DP) + (row * DP + p * 8);
+        } else {
+          int64_t grow = tile * TR + row;
+          grow = grow < B ? grow : B - 1;
+          src = z + grow * DP + p * 8;
+        }
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(zbuf + (size_t)buf * TILE_BYTES + (size_t)(L - lane) * 16),
+                                         16, 0, 0);
+      }
+    }
+  };
+
+  float err = 0.f;
+  int64_t tile = blockIdx.x;
+  if (tile < ntiles) stage(tile, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();  // first tile landed
+  // Per tile: [stage the next tile | scores -> red[parity]], wait for the own DMA, ONE barrier, [row winner, z_q row].
+  // Safe with one barrier: the buffer a stage overwrites was last read before the previous tile's barrier; red[parity] is
+  // rewritten two tiles later, i.e. after the next barrier, which no wave passes before all have read this tile's.
+#ifdef VQ_BS_TIMING
+  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+#define VQ_T(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define VQ_T(k)
+#endif
+  for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
+    if (tile + gridDim.x < ntiles) stage(tile + gridDim.x, (it + 1) & 1);
+    VQ_T(0)
+    float* rs = red_s + (it & 1) * RED;
+    int* rc = red_c + (it & 1) * RED;
+    const float zz = vq_bs_tile<DP, NCT, IL>(zbuf + (size_t)(it & 1) * TILE_BYTES, b, bias, rs, rc);
+    VQ_T(1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed
+    VQ_T(2)
+    __syncthreads();
+    VQ_T(3)
+    // ---- thread (row = tid / 8, part = tid % 8): the 8 waves' candidates of its row - ascending wave = ascending code,
+    // strict > keeps the lowest code on ties - then pieces part, part + 8, .. of the winner's image row -> z_q (un-swizzled)
+    const int row = tid >> 3, part = tid & 7;
+    float best = rs[row];
+    int code = rc[row];
+#pragma unroll
+    for (int w = 1; w < VQ_BS_WAVES; ++w) {
+      const float sc = rs[w * TR + row];
+      const int cc = rc[w * TR + row];
+      const bool better = sc > best;
+      best = better ? sc : best;
+      code = better ? cc : code;
+    }
+    code = (unsigned)code < (unsigned)(128 * NCT) ? code : 0;  // all-NaN row: no score equals the maximum
+    const int64_t grow = tile * TR + row;
+    const char* wrow = gimg + (size_t)(unsigned)(code * (DP * 2) + (code >> 6) * (CT * 4));  // chunk * CHB + (code % CT) * DP * 2
+    constexpr int NJ = (CPR + 7) / 8;
+    u16x8 v[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int p = (part + 8 * j) % CPR;
+      v[j] = *reinterpret_cast<const u16x8*>(wrow + (size_t)((p ^ (code & SWZ_MASK)) << 4));
+    }
+    // the loads are consumed on every path: nothing of them is left in flight behind the conditional stores (a pending
+    // load would make the compiler wait for ALL vector memory, the next tile's DMA included, at the top of the loop)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(v[j]));
+    VQ_T(4)
+    if (grow < B) {
+      if (part == 0) {
+        idx_out[grow] = code;
+        err += __fmaf_rn(-2.0f, best, zz);  // |z - w|^2 = |z|^2 - 2 (z.w - |w|^2/2)
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int p = part + 8 * j;
+        if (CPR % 8 == 0 || p < CPR) *reinterpret_cast<u16x8*>(z_q + grow * DP + p * 8) = v[j];
+      }
+    }
+    VQ_T(5)
+  }
+#ifdef VQ_BS_TIMING
+  if ((blockIdx.x == 0 || blockIdx.x == 200) && lane == 0 && (wave == 0 || wave == 7))
+    printf("blk %d wave %d: stage %llu scores %llu dmawait %llu barrier %llu scan+img %llu stores %llu (s_memtime ticks, 100 MHz)\n", (int)blockIdx.x,
+           wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+#endif
+  err = ceeg_wave_sum(err);
+  if (lane == 0) lds_red[wave] = err;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < VQ_BS_WAVES; ++w) t += lds_red[w];
+    err_part[blockIdx.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ histogram
 // slice g covers rows [g*rows_per, (g+1)*rows_per); counts in LDS (integer adds commute: deterministic)
 __global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int64_t rows_per,
@@ -781,7 +1078,7 @@ struct VqFwdWs {
 size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_bytes, VqFwdWs* out) {
   const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
   const int n_ep = (n_e + CT - 1) / CT * CT;
-  const int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
+  const int64_t nblk = (B + 127) / 128 + 256;  // upper bound over the kernels' partial-sum slots
   CeegWs a(ws, ws_bytes);
   size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4, 1) +
                 ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)vq_nslice(B) * n_e, 4);
@@ -810,9 +1107,32 @@ void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int
     hipLaunchKernelGGL((vq_main_f32<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
                        reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
 }
+bool vq_bs_off() {
+  static const bool off = getenv("CEEG_VQ_BF16_BS") && getenv("CEEG_VQ_BF16_BS")[0] == '0';  // checker's switch: row-stationary kernel
+  return off;
+}
+template <int DP, int NCT>
+int64_t launch_bf16_bs(const void* z, const VqFwdWs& w, int64_t B, void* z_q, int64_t* idx, hipStream_t st) {
+  const int64_t ntiles = (B + VQ_BS_TR - 1) / VQ_BS_TR;
+  const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);  // one persistent workgroup per CU
+  const size_t lds = 2 * (size_t)VQ_BS_TR * DP * 2 + 2 * (size_t)VQ_BS_WAVES * VQ_BS_TR * 8 + VQ_BS_WAVES * 4;
+  static const int il = getenv("CEEG_VQ_BS_IL") ? atoi(getenv("CEEG_VQ_BS_IL")) : 0;
+  auto* kern = il == 2 ? vq_main_bf16_bs<DP, NCT, 2> : (il == 1 ? vq_main_bf16_bs<DP, NCT, 1> : vq_main_bf16_bs<DP, NCT, 0>);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(VQ_BS_WAVES * 64), lds, st, reinterpret_cast<const unsigned short*>(z),
+                     reinterpret_cast<const unsigned short*>(w.img), B, reinterpret_cast<unsigned short*>(z_q), idx, w.err_part);
+  return (int64_t)grid;
+}
+// returns the number of err_part slots the launched kernel fills
 template <int DP>
-void launch_bf16(const void* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, void* z_q,
-                 int64_t* idx, int64_t nblk, hipStream_t st) {
+int64_t launch_bf16(const void* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, void* z_q,
+                    int64_t* idx, int64_t nblk, hipStream_t st) {
+  if constexpr (DP >= 64) {
+    if (D == DP && !vq_bs_off()) {  // whole codebook in one workgroup's registers
+      if (n_ep == 128) return launch_bf16_bs<DP, 1>(z, w, B, z_q, idx, st);
+      if (n_ep == 256) return launch_bf16_bs<DP, 2>(z, w, B, z_q, idx, st);
+      if (n_ep == 512) return launch_bf16_bs<DP, 4>(z, w, B, z_q, idx, st);
+    }
+  }
   const size_t lds = 2 * (64 * DP * 2 + 64 * 4) + 256 * 4 + VQ_WAVES * 4;
   if (D == DP)
     hipLaunchKernelGGL((vq_main_bf16<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st,
@@ -822,6 +1142,7 @@ void launch_bf16(const void* z, const float* W, const VqFwdWs& w, int64_t B, int
     hipLaunchKernelGGL((vq_main_bf16<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(z), W, w.ee, reinterpret_cast<const unsigned short*>(w.img), B,
                        n_e, D, n_ep, reinterpret_cast<unsigned short*>(z_q), idx, w.err_part);
+  return nblk;
 }
 
 }  // namespace
@@ -844,7 +1165,7 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
   const int n_ep = (n_e + CT - 1) / CT * CT;
-  const int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
+  int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
 
   const int prep_blocks = (int)(((int64_t)n_ep * DP + 255) / 256 < 1024 ? ((int64_t)n_ep * DP + 255) / 256 : 1024);
   if (dtype == CEEG_BF16)
@@ -866,10 +1187,10 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
     }
   } else {
     switch (DP) {
-      case 32: launch_bf16<32>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
-      case 64: launch_bf16<64>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
-      case 128: launch_bf16<128>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
-      case 256: launch_bf16<256>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 32: nblk = launch_bf16<32>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 64: nblk = launch_bf16<64>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 128: nblk = launch_bf16<128>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
+      case 256: nblk = launch_bf16<256>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
       default: return CEEG_EUNSUPPORTED;
     }
   }
