@@ -502,9 +502,9 @@ __global__ __launch_bounds__(VQ_THREADS, 2) void vq_main_bf16(
       bf16x8_t ob;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float df = w[j] - ceeg_bf16_to_f32(a[rt][s][j]);
-        e = __fmaf_rn(df, df, e);
         ob[j] = (__bf16)w[j];  // v_cvt_pk_bf16_f32 (RNE, NaN stays NaN)
+        const float df = (float)ob[j] - ceeg_bf16_to_f32(a[rt][s][j]);  // against the row z_q returns: loss = (1+beta) mean((z_q - z)^2)
+        e = __fmaf_rn(df, df, e);
       }
       const u16x8 o = __builtin_bit_cast(u16x8, ob);
       if constexpr (EXACT) {
@@ -538,6 +538,7 @@ typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 constexpr int VQ_BS_WAVES = 8;
 constexpr int VQ_BS_TR = 64;  // rows per LDS tile
 
+
 template <int CTRL>
 __device__ __forceinline__ float vq_dpp_f(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false)); }
 template <int CTRL>
@@ -566,14 +567,21 @@ __device__ __forceinline__ int vq_xrow_min(int v) {
 // in flight writes the OTHER buffer; the kernel waits for it explicitly before the barrier that publishes it).
 // The codebook is the MFMA's A operand, so lane (r, q) ends up with ONE latent row (r) and 4 NCT codes (16 ct + 4 q + i):
 // the row maximum is a per-lane chain, then two cross-row steps (lanes r, r+16, r+32, r+48); the winner's code is the
-// lowest one whose score equals the maximum.  Returns |z_row|^2 of row tid / 8 (all 8 threads of the row hold it).
-template <int DP, int NCT, int IL>
+// lowest one whose score equals the maximum.  hook(k) runs before row tile k (k = 0..3) and after the last one (k = 4):
+// the caller hangs the next tile's DMA and the previous tile's output phase there, under this tile's MFMAs.
+// Returns |z_row|^2 of row tid / 8 (all 8 threads of the row hold it).
+template <int K>
+struct VqStep { static constexpr int value = K; };
+
+
+template <int DP, int NCT, typename Hook>
 __device__ __forceinline__ float vq_bs_tile(const char* __restrict__ zb, const u16x8 (&b)[NCT][DP / 32], const f32x4 (&bias)[NCT],
-                                            float* __restrict__ red_s, int* __restrict__ red_c) {
+                                            float* __restrict__ red_s, int* __restrict__ red_c, Hook&& hook) {
   constexpr int KS = DP / 32;
   constexpr int CPR = DP / 8;
   constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
   constexpr int TR = VQ_BS_TR;
+  static_assert(TR == 64, "four row tiles, five hook points");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   // |z_row|^2: 8 threads per row, v_dot2_f32_bf16 over their pieces (any order: the swizzle does not matter), xor butterfly
@@ -603,75 +611,72 @@ __device__ __forceinline__ float vq_bs_tile(const char* __restrict__ zb, const u
   const char* pa[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) pa[j] = zb + (size_t)r * DP * 2 + ((((4 * j + q) & SWZ_MASK) ^ (r & SWZ_MASK)) << 4) + (((4 * j + q) & ~SWZ_MASK) << 4);
-  auto scores = [&](int rt, f32x4 (&acc)[NCT]) {
+  auto scores = [&](int rt, f32x4 (&c)[NCT]) {
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const u16x8 a = *reinterpret_cast<const u16x8*>(pa[s % NA] + rt * 16 * DP * 2 + (s / NA) * NA * 64);
 #pragma unroll
       for (int ct = 0; ct < NCT; ++ct)
-        acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[ct][s]), __builtin_bit_cast(bf16x8_t, a),
-                                                         s == 0 ? bias[ct] : acc[ct], 0, 0, 0);
+        c[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, b[ct][s]), __builtin_bit_cast(bf16x8_t, a),
+                                                       s == 0 ? bias[ct] : c[ct], 0, 0, 0);
     }
   };
-  auto winner = [&](int rt, const f32x4 (&acc)[NCT]) {
-    float m = acc[0][0];
+  auto winner = [&](int rt, const f32x4 (&c)[NCT]) {
+    float m = c[0][0];
 #pragma unroll
     for (int ct = 0; ct < NCT; ++ct)
 #pragma unroll
-      for (int i = (ct == 0 ? 1 : 0); i < 4; ++i) m = vq_max(m, acc[ct][i]);
+      for (int i = (ct == 0 ? 1 : 0); i < 4; ++i) m = vq_max(m, c[ct][i]);
     m = vq_xrow_max<16>(m);
     m = vq_xrow_max<32>(m);
     int cand = 1 << 20;  // "not mine"
 #pragma unroll
     for (int ct = NCT - 1; ct >= 0; --ct)
 #pragma unroll
-      for (int i = 3; i >= 0; --i) cand = (acc[ct][i] == m) ? ct * 16 + i : cand;
+      for (int i = 3; i >= 0; --i) cand = (c[ct][i] == m) ? ct * 16 + i : cand;
     cand += wave * 16 * NCT + 4 * q;
     cand = vq_xrow_min<16>(cand);
     cand = vq_xrow_min<32>(cand);
-    // all four lanes of a row hold (m, cand): even q stores the score, odd q the code - one branch-free LDS store, so the
-    // four row tiles stay one basic block and their MFMAs and epilogues can be interleaved
+    // all four lanes of a row hold (m, cand): even q stores the score, odd q the code - one branch-free LDS store
     wdst[rt * 16] = (q & 1) ? cand : __float_as_int(m);
   };
-  if constexpr (IL) {
-    // software pipeline: the MFMAs of row tile rt are issued between the VALU of row tile rt - 1's winner search
-    __builtin_amdgcn_sched_barrier(0);
-    f32x4 acc[2][NCT];
-    scores(0, acc[0]);
-#pragma unroll
-    for (int rt = 1; rt < TR / 16; ++rt) {
-      scores(rt, acc[rt & 1]);
-      winner(rt - 1, acc[(rt - 1) & 1]);
-    }
-    winner(TR / 16 - 1, acc[(TR / 16 - 1) & 1]);
-#pragma unroll
-    for (int k = 0; k < KS; ++k) {  // prologue: reads + MFMAs of row tile 0
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, NCT, 0);
-    }
-#pragma unroll
-    for (int rt = 1; rt < TR / 16; ++rt)
-#pragma unroll
-      for (int k = 0; k < KS; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          __builtin_amdgcn_sched_group_barrier(0x002, IL, 0);
-        }
-      }
-  } else {
-#pragma unroll
-    for (int rt = 0; rt < TR / 16; ++rt) {
-      f32x4 acc[NCT];
-      scores(rt, acc);
-      winner(rt, acc);
-    }
+  {
+    f32x4 acc[NCT];
+    hook(VqStep<0>{});
+    scores(0, acc);
+    winner(0, acc);
+    hook(VqStep<1>{});
+    scores(1, acc);
+    winner(1, acc);
+    hook(VqStep<2>{});
+    scores(2, acc);
+    winner(2, acc);
+    hook(VqStep<3>{});
+    scores(3, acc);
+    winner(3, acc);
+    hook(VqStep<4>{});
   }
   return zz;
 }
 
-template <int DP, int NCT, int IL>
+// the 8 waves' candidates of one row: ascending wave = ascending code, strict > keeps the lowest code on ties
+// (__restrict__ parameters for the same reason as vq_bs_tile's: these reads run while the next tile's DMA is in flight)
+__device__ __forceinline__ void vq_bs_row_winner(const float* __restrict__ rs, const int* __restrict__ rc, int row, int n_codes,
+                                                 float& best, int& code) {
+  best = rs[row];
+  code = rc[row];
+#pragma unroll
+  for (int w = 1; w < VQ_BS_WAVES; ++w) {
+    const float sc = rs[w * VQ_BS_TR + row];
+    const int cc = rc[w * VQ_BS_TR + row];
+    const bool better = sc > best;
+    best = better ? sc : best;
+    code = better ? cc : code;
+  }
+  code = (unsigned)code < (unsigned)n_codes ? code : 0;  // all-NaN row: no score equals the maximum
+}
+
+template <int DP, int NCT>
 __global__ __launch_bounds__(VQ_BS_WAVES * 64, 1) void vq_main_bf16_bs(
     const unsigned short* __restrict__ z, const unsigned short* __restrict__ img, int64_t B,
     unsigned short* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
@@ -684,6 +689,9 @@ __global__ __launch_bounds__(VQ_BS_WAVES * 64, 1) void vq_main_bf16_bs(
   constexpr int TILE_BYTES = TR * DP * 2;
   constexpr int THREADS = VQ_BS_WAVES * 64;
   constexpr int PIECES = TR * CPR;                  // 16-byte pieces per tile
+  constexpr int NJS = PIECES / THREADS;             // DMA instructions per thread and tile (1, 2 or 4)
+  static_assert(PIECES % THREADS == 0 && (NJS == 1 || NJS == 2 || NJS == 4), "D in {64, 128, 256}");
+  constexpr int NJ = (CPR + 7) / 8;                 // z_q pieces per thread and row
   constexpr int RED = VQ_BS_WAVES * TR;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -711,100 +719,141 @@ __global__ __launch_bounds__(VQ_BS_WAVES * 64, 1) void vq_main_bf16_bs(
   }
 
   const int64_t ntiles = (B + TR - 1) / TR;
-  // LDS slot L of a tile (16 bytes each) holds piece (L % CPR) ^ (row & SWZ_MASK) of row L / CPR: conflict-free operand reads
-  auto stage = [&](int64_t tile, int buf) {
-    const bool full = (tile + 1) * TR <= B;  // uniform: no per-row clamp on the common path
+  // DMA instruction j of a tile: LDS slot L = j * THREADS + tid (16 bytes each) holds piece (L % CPR) ^ (row & SWZ_MASK) of
+  // row L / CPR: conflict-free operand reads
+  auto stage = [&](int64_t tile, int buf, int j) {
+    const int L = j * THREADS + tid;
+    const int row = L / CPR, pos = L % CPR;
+    const int p = pos ^ (row & SWZ_MASK);
+    const unsigned short* src;
+    if ((tile + 1) * TR <= B) {  // uniform: no per-row clamp on the common path
+      src = z + tile * (TR * DP) + (row * DP + p * 8);
+    } else {
+      int64_t grow = tile * TR + row;
+      grow = grow < B ? grow : B - 1;
+      src = z + grow * DP + p * 8;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(zbuf + (size_t)buf * TILE_BYTES + (size_t)(L - lane) * 16),
+                                     16, 0, 0);
+  };
+
+  // output phase of a tile, split so that it can run under the NEXT tile's MFMAs: thread (row = tid / 8, part = tid % 8)
+  // finds its row's winner, part 0 writes the index and takes the row's squared error, all 8 fetch pieces part, part + 8,
+  // .. of the winner's image row (un-swizzling them) - and, later, store them to z_q
+  const int orow = tid >> 3, part = tid & 7;
+  float err = 0.f;
+  u16x8 ov[NJ];
+  auto out_fetch = [&](int64_t tile, int parity, float zz) {
+    float best;
+    int code;
+    vq_bs_row_winner(red_s + parity * RED, red_c + parity * RED, orow, 128 * NCT, best, code);
+    const int64_t grow = tile * TR + orow;
+    if (part == 0 && grow < B) idx_out[grow] = code;
+    const char* wrow = gimg + (size_t)(unsigned)(code * (DP * 2) + (code >> 6) * (CT * 4));  // chunk * CHB + (code % CT) * DP * 2
 #pragma unroll
-    for (int j0 = 0; j0 < PIECES; j0 += THREADS) {
-      const int L = j0 + tid;
-      if (PIECES % THREADS == 0 || L < PIECES) {
-        const int row = L / CPR, pos = L % CPR;
-        const int p = pos ^ (row & SWZ_MASK);
-        const unsigned short* src;
-        if (full) {
-          src = z + tile * (TR * DP) + (row * DP + p * 8);
-        } else {
-          int64_t grow = tile * TR + row;
-          grow = grow < B ? grow : B - 1;
-          src = z + grow * DP + p * 8;
+    for (int j = 0; j < NJ; ++j) {
+      const int p = (part + 8 * j) % CPR;
+      ov[j] = *reinterpret_cast<const u16x8*>(wrow + (size_t)((p ^ (code & SWZ_MASK)) << 4));
+    }
+    // squared error of the row against the bf16 codebook row z_q returns: |z|^2 - 2 (z.w - |w|^2/2), from numbers the
+    // tile already has.  That difference loses its digits when the row sits (almost) on its code; such rows - none on
+    // spread-out data, so the branch is wave-uniformly skipped - are summed explicitly from z (re-read) and the fetched row
+    float e = __fmaf_rn(-2.0f, best, zz);
+    const bool close = grow < B && !(e >= zz * 0.015625f);
+    if (__any(close)) {
+      float ex = 0.f;
+      if (close) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int p = part + 8 * j;
+          if (CPR % 8 == 0 || p < CPR) {
+            const u16x8 zp = *reinterpret_cast<const u16x8*>(z + grow * DP + p * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const float df = ceeg_bf16_to_f32(ov[j][k]) - ceeg_bf16_to_f32(zp[k]);
+              ex = __fmaf_rn(df, df, ex);
+            }
+          }
         }
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(zbuf + (size_t)buf * TILE_BYTES + (size_t)(L - lane) * 16),
-                                         16, 0, 0);
+      }
+      ex += vq_dpp_f<0xB1>(ex);
+      ex += vq_dpp_f<0x4E>(ex);
+      ex += vq_dpp_f<0x141>(ex);
+      e = close ? ex : e;
+    }
+    if (part == 0 && grow < B) err += e;
+  };
+  auto out_store = [&](int64_t tile) {
+    // the loads are consumed on every path: nothing of them is left in flight behind the conditional stores (a pending
+    // load would make the compiler wait for ALL vector memory, the next tile's DMA included, at the next use of a register)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(ov[j]));
+    const int64_t grow = tile * TR + orow;
+    if (grow < B) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int p = part + 8 * j;
+        if (CPR % 8 == 0 || p < CPR) *reinterpret_cast<u16x8*>(z_q + grow * DP + p * 8) = ov[j];
       }
     }
   };
 
-  float err = 0.f;
   int64_t tile = blockIdx.x;
-  if (tile < ntiles) stage(tile, 0);
+  if (tile < ntiles) {
+#pragma unroll
+    for (int j = 0; j < NJS; ++j) stage(tile, 0, j);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();  // first tile landed
-  // Per tile: [stage the next tile | scores -> red[parity]], wait for the own DMA, ONE barrier, [row winner, z_q row].
-  // Safe with one barrier: the buffer a stage overwrites was last read before the previous tile's barrier; red[parity] is
-  // rewritten two tiles later, i.e. after the next barrier, which no wave passes before all have read this tile's.
 #ifdef VQ_BS_TIMING
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = __builtin_amdgcn_s_memtime();
 #define VQ_T(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; }
 #else
 #define VQ_T(k)
 #endif
+  // Per tile: scores -> red[parity]; hung between its row tiles, the next tile's DMA and the PREVIOUS tile's output phase
+  // (winner + image fetch, z_q stores two row tiles later); then the wait for the own DMA and ONE barrier.  Safe with one
+  // barrier: the buffer a DMA overwrites was last read before the previous barrier; red[parity] is read during the next
+  // tile, i.e. before the next barrier, and rewritten only after it.
+  float zz_prev = 0.f;
+  int64_t prev = -1;
   for (int it = 0; tile < ntiles; ++it, tile += gridDim.x) {
-    if (tile + gridDim.x < ntiles) stage(tile + gridDim.x, (it + 1) & 1);
+    const int64_t next = tile + gridDim.x;
+    const bool has_next = next < ntiles;
+    const float zz = vq_bs_tile<DP, NCT>(zbuf + (size_t)(it & 1) * TILE_BYTES, b, bias, red_s + (it & 1) * RED, red_c + (it & 1) * RED,
+                                         [&](auto step) {
+                                           constexpr int K = decltype(step)::value;
+                                           if constexpr (K == 1) {
+                                             if (has_next) {
+#pragma unroll
+                                               for (int j = 0; j < NJS; ++j) stage(next, (it + 1) & 1, j);
+                                             }
+                                           }
+                                           if constexpr (K == 2) {
+                                             if (prev >= 0) out_fetch(prev, (it + 1) & 1, zz_prev);
+                                           }
+                                           if constexpr (K == 4) {
+                                             if (prev >= 0) out_store(prev);
+                                           }
+                                         });
     VQ_T(0)
-    float* rs = red_s + (it & 1) * RED;
-    int* rc = red_c + (it & 1) * RED;
-    const float zz = vq_bs_tile<DP, NCT, IL>(zbuf + (size_t)(it & 1) * TILE_BYTES, b, bias, rs, rc);
-    VQ_T(1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next tile has landed
-    VQ_T(2)
+    VQ_T(1)
     __syncthreads();
-    VQ_T(3)
-    // ---- thread (row = tid / 8, part = tid % 8): the 8 waves' candidates of its row - ascending wave = ascending code,
-    // strict > keeps the lowest code on ties - then pieces part, part + 8, .. of the winner's image row -> z_q (un-swizzled)
-    const int row = tid >> 3, part = tid & 7;
-    float best = rs[row];
-    int code = rc[row];
-#pragma unroll
-    for (int w = 1; w < VQ_BS_WAVES; ++w) {
-      const float sc = rs[w * TR + row];
-      const int cc = rc[w * TR + row];
-      const bool better = sc > best;
-      best = better ? sc : best;
-      code = better ? cc : code;
-    }
-    code = (unsigned)code < (unsigned)(128 * NCT) ? code : 0;  // all-NaN row: no score equals the maximum
-    const int64_t grow = tile * TR + row;
-    const char* wrow = gimg + (size_t)(unsigned)(code * (DP * 2) + (code >> 6) * (CT * 4));  // chunk * CHB + (code % CT) * DP * 2
-    constexpr int NJ = (CPR + 7) / 8;
-    u16x8 v[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int p = (part + 8 * j) % CPR;
-      v[j] = *reinterpret_cast<const u16x8*>(wrow + (size_t)((p ^ (code & SWZ_MASK)) << 4));
-    }
-    // the loads are consumed on every path: nothing of them is left in flight behind the conditional stores (a pending
-    // load would make the compiler wait for ALL vector memory, the next tile's DMA included, at the top of the loop)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) asm volatile("" ::"v"(v[j]));
-    VQ_T(4)
-    if (grow < B) {
-      if (part == 0) {
-        idx_out[grow] = code;
-        err += __fmaf_rn(-2.0f, best, zz);  // |z - w|^2 = |z|^2 - 2 (z.w - |w|^2/2)
-      }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int p = part + 8 * j;
-        if (CPR % 8 == 0 || p < CPR) *reinterpret_cast<u16x8*>(z_q + grow * DP + p * 8) = v[j];
-      }
-    }
-    VQ_T(5)
+    VQ_T(2)
+    zz_prev = zz;
+    prev = tile;
   }
+  if (prev >= 0) {  // the last tile's output phase (its red[] was published by the loop's last barrier)
+    const int last_parity = (int)(((prev - blockIdx.x) / gridDim.x) & 1);
+    out_fetch(prev, last_parity, zz_prev);
+    out_store(prev);
+  }
+  VQ_T(3)
 #ifdef VQ_BS_TIMING
   if ((blockIdx.x == 0 || blockIdx.x == 200) && lane == 0 && (wave == 0 || wave == 7))
-    printf("blk %d wave %d: stage %llu scores %llu dmawait %llu barrier %llu scan+img %llu stores %llu (s_memtime ticks, 100 MHz)\n", (int)blockIdx.x,
-           wave, tacc[0], tacc[1], tacc[2], tacc[3], tacc[4], tacc[5]);
+    printf("blk %d wave %d: tile %llu dmawait %llu barrier %llu drain %llu cycles\n", (int)blockIdx.x, wave, tacc[0], tacc[1], tacc[2], tacc[3]);
 #endif
   err = ceeg_wave_sum(err);
   if (lane == 0) lds_red[wave] = err;
@@ -1107,18 +1156,16 @@ void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int
     hipLaunchKernelGGL((vq_main_f32<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
                        reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
 }
-bool vq_bs_off() {
-  static const bool off = getenv("CEEG_VQ_BF16_BS") && getenv("CEEG_VQ_BF16_BS")[0] == '0';  // checker's switch: row-stationary kernel
-  return off;
+bool vq_bs_off() {  // checker's switch (read per call): CEEG_VQ_BF16_BS=0 selects the row-stationary kernel
+  const char* e = getenv("CEEG_VQ_BF16_BS");
+  return e && e[0] == '0';
 }
 template <int DP, int NCT>
 int64_t launch_bf16_bs(const void* z, const VqFwdWs& w, int64_t B, void* z_q, int64_t* idx, hipStream_t st) {
   const int64_t ntiles = (B + VQ_BS_TR - 1) / VQ_BS_TR;
   const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);  // one persistent workgroup per CU
   const size_t lds = 2 * (size_t)VQ_BS_TR * DP * 2 + 2 * (size_t)VQ_BS_WAVES * VQ_BS_TR * 8 + VQ_BS_WAVES * 4;
-  static const int il = getenv("CEEG_VQ_BS_IL") ? atoi(getenv("CEEG_VQ_BS_IL")) : 0;
-  auto* kern = il == 2 ? vq_main_bf16_bs<DP, NCT, 2> : (il == 1 ? vq_main_bf16_bs<DP, NCT, 1> : vq_main_bf16_bs<DP, NCT, 0>);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(VQ_BS_WAVES * 64), lds, st, reinterpret_cast<const unsigned short*>(z),
+  hipLaunchKernelGGL((vq_main_bf16_bs<DP, NCT>), dim3(grid), dim3(VQ_BS_WAVES * 64), lds, st, reinterpret_cast<const unsigned short*>(z),
                      reinterpret_cast<const unsigned short*>(w.img), B, reinterpret_cast<unsigned short*>(z_q), idx, w.err_part);
   return (int64_t)grid;
 }

@@ -98,6 +98,34 @@ def test_bf16_indices_within_rounding_bound(B, n_e, D):
     np.testing.assert_allclose(zc.grad.float().cpu().numpy(), dz_ref.numpy(), rtol=1e-2, atol=1e-2)
 
 
+@pytest.mark.parametrize("B,n_e,D", [(1, 512, 256), (63, 512, 256), (65, 100, 256), (20001, 512, 256), (70000, 256, 128),
+                                     (4097, 128, 64), (33333, 512, 64), (129, 500, 128)])
+def test_bf16_codebook_stationary_kernel_equals_row_stationary(B, n_e, D, monkeypatch):
+    """The persistent codebook-in-registers bf16 kernel (D in {64,128,256}, padded codebook of 128/256/512 codes) against
+    the row-stationary one it replaced (CEEG_VQ_BF16_BS=0): same MFMA products in the same k order, so codes and z_q are
+    bitwise equal; the loss differs only in how the squared error is summed.  Shapes: a single row, ragged last tiles,
+    padded codebooks (100 -> 128, 500 -> 512), more tiles than workgroups (70000 / 64 > 256: the persistent loop), and
+    duplicate codes (ties must go to the lowest index in both)."""
+    torch.manual_seed(B + n_e + D)
+    W = torch.randn(n_e, D)
+    W[n_e // 2] = W[3]  # an exact tie between codes 3 and n_e // 2
+    z = torch.randn(B, D)
+    z[: min(B, 7)] = W[3]  # rows that sit on the tied pair
+    z = z.to(torch.bfloat16).cuda()
+    vq = _mod(n_e, D, 0.25, W.numpy(), one_hot=False)
+    monkeypatch.setenv("CEEG_VQ_BF16_BS", "1")
+    l1, q1, p1, _, i1 = vq(z)
+    monkeypatch.setenv("CEEG_VQ_BF16_BS", "0")
+    l0, q0, p0, _, i0 = vq(z)
+    assert torch.equal(i1, i0) and torch.equal(q1, q0) and torch.equal(p1, p0)
+    assert (i1[: min(B, 7), 0] == 3).all()
+    assert torch.equal(q1, vq.embedding.weight[i1[:, 0]].to(torch.bfloat16))
+    # both kernels: loss = (1 + beta) mean((z_q - z)^2) for the bf16 z_q they return (rows sitting exactly on a code add 0)
+    want = 1.25 * ((q1.double() - z.double()) ** 2).mean().item()
+    np.testing.assert_allclose(l1.item(), want, rtol=1e-4, atol=1e-12)
+    np.testing.assert_allclose(l0.item(), want, rtol=1e-4, atol=1e-12)
+
+
 def test_large_properties_and_determinism():
     """Config-3-like size-independent properties: z_q rows ARE codebook rows, histogram sums to B,
     idempotence (quantising z_q returns the same codes), bitwise run-to-run reproducibility."""
