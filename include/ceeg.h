@@ -58,7 +58,11 @@ int ceeg_check_device(void);
  *                  fmaf chain from 0 (bit-identical to oracle/ceeg_oracle.c:vq_forward_f32).
  * dtype CEEG_BF16: z,z_q bf16 (codebook stays fp32, rounded RNE to bf16 for the GEMM);
  *                  v_mfma_f32_16x16x32_bf16, fp32 accumulate; score = dot - ee/2 (row-constant zz
- *                  dropped); no reference counterpart.
+ *                  dropped); no reference counterpart.  z_q[b] = bf16(W[idx[b]]) and
+ *                  sqerr is taken against that returned row.  Two kernels, bitwise-equal idx and z_q:
+ *                  D in {64,128,256} with n_e padded to 128/256/512 runs with the codebook resident in
+ *                  registers (persistent, one workgroup per CU); every other shape with the rows in
+ *                  registers.  Environment CEEG_VQ_BF16_BS=0 forces the second one (a checker's switch).
  *
  * z [B,D], W [n_e,D] fp32, z_q [B,D] (dtype), idx [B] int64, loss/perplexity: 1 float each (device),
  * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 16384, B >= 1
