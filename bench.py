@@ -11,7 +11,8 @@ with every input already resident in HBM.  value = positive directed edges proce
 Multi-GPU: one graph shard per rank (weak scaling), gradients averaged with one RCCL all-reduce per step.
 
 Extra (my own measurements, not the driver's contract): --workload vq (BASELINE.json configs[2]) and
---workload cvgae (configs[3]: conditional VGAE + VQ on 64 collated graphs x 100k edges per rank).
+--workload cvgae (configs[3]: conditional VGAE + VQ on 64 collated graphs x 100k edges per rank), --workload gat
+(next-row N1: GATConv forward + backward on the configs[1] graph).
 """
 import argparse
 import json
@@ -37,7 +38,8 @@ def parse():
     ap.add_argument("--in-dim", type=int, default=128)
     ap.add_argument("--latent", type=int, default=128)
     ap.add_argument("--codes", type=int, default=512)
-    ap.add_argument("--workload", default="vgae", choices=["vgae", "vq", "cvgae"])
+    ap.add_argument("--gat-heads", type=int, default=1)
+    ap.add_argument("--workload", default="vgae", choices=["vgae", "vq", "cvgae", "gat"])
     ap.add_argument("--graphs", type=int, default=64)           # cvgae (configs[3]): graphs per rank
     ap.add_argument("--edges-per-graph", type=int, default=100_000)
     ap.add_argument("--nodes-per-graph", type=int, default=6_250)
@@ -140,6 +142,38 @@ def main():
                           "config": {"workload": f"VectorQuantizer fwd {B}x{n_e}x{D}"},
                           "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
                                        "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None}}))
+        return
+
+    if args.workload == "gat":
+        # next-row N1: the graph layer the reference instantiates (scripts/models.py:106), forward +
+        # backward on the config-2 graph; heads = 1, in_dim -> 2 * latent as the encoder's first layer
+        from causal_eeg_vae_amd import GATConv
+        N, E = args.nodes, args.edges
+        ei = synth_event_graph(N, E, seed=1000 + rank, device=dev)
+        x = synth_features(N, args.in_dim, seed=1000 + rank, device=dev).requires_grad_(True)
+        graph = GATConv.attention_graph(ei, N)
+        torch.manual_seed(0)
+        conv = GATConv(args.in_dim, 2 * args.latent, heads=args.gat_heads).to(dev)
+
+        def once():
+            out = conv(x, graph)
+            out.backward(torch.ones_like(out))
+            x.grad = None
+            conv.zero_grad(set_to_none=True)
+
+        for _ in range(args.warmup):
+            once()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            once()
+        barrier()
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "GATConv fwd+bwd edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"GATConv({args.in_dim}, {2 * args.latent}, heads={args.gat_heads}) forward + backward, "
+                                                 f"synthetic power-law event graph {N} nodes / {E} edges per GPU"}}))
         return
 
     if args.workload == "cvgae":

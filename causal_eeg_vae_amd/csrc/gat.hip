@@ -157,6 +157,131 @@ int gat_blocks(int64_t N) {
   if (b < 1) b = 1;
   return (int)(b < GAT_MAX_BLOCKS ? b : GAT_MAX_BLOCKS);
 }
+// ---- attention scores a_src[h][n] = <xp[n, h, :], att_src[h, :]> (and a_dst) in ONE pass over xp: LPR lanes per (n, h),
+// one float4 each, xor butterfly inside the group (fixed order).  Stands behind (x_proj * att).sum(-1) of PyG GATConv.
+template <int LPR>
+__global__ __launch_bounds__(256) void gat_scores_fwd_kernel(const float* __restrict__ xp, int64_t ldx, const float* __restrict__ att_src,
+                                                             const float* __restrict__ att_dst, int64_t N, int H, int C,
+                                                             float* __restrict__ a_src, float* __restrict__ a_dst) {
+  const int l = threadIdx.x % LPR;
+  const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
+  const int64_t ngrp = (int64_t)gridDim.x * 256 / LPR;
+  const int64_t items = N * H;
+  const bool live = 4 * l < C;
+  for (int64_t it0 = grp; it0 < items + ngrp; it0 += 2 * ngrp) {  // two items in flight per group
+    const int64_t itA = it0, itB = it0 + ngrp;
+    const bool okA = itA < items, okB = itB < items;
+    if (!okA && !okB) break;
+    const int64_t nA = okA ? itA / H : 0, nB = okB ? itB / H : 0;
+    const int hA = okA ? (int)(itA - nA * H) : 0, hB = okB ? (int)(itB - nB * H) : 0;
+    float4 xA = make_float4(0.f, 0.f, 0.f, 0.f), xB = xA, sA = xA, dA = xA, sB = xA, dB = xA;
+    if (live) {
+      xA = *reinterpret_cast<const float4*>(xp + nA * ldx + hA * C + 4 * l);
+      xB = *reinterpret_cast<const float4*>(xp + nB * ldx + hB * C + 4 * l);
+      sA = *reinterpret_cast<const float4*>(att_src + hA * C + 4 * l);
+      dA = *reinterpret_cast<const float4*>(att_dst + hA * C + 4 * l);
+      sB = *reinterpret_cast<const float4*>(att_src + hB * C + 4 * l);
+      dB = *reinterpret_cast<const float4*>(att_dst + hB * C + 4 * l);
+    }
+    float vs0 = gat_dot4(xA, sA), vd0 = gat_dot4(xA, dA), vs1 = gat_dot4(xB, sB), vd1 = gat_dot4(xB, dB);
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) {
+      vs0 += __shfl_xor(vs0, o, 64);
+      vd0 += __shfl_xor(vd0, o, 64);
+      vs1 += __shfl_xor(vs1, o, 64);
+      vd1 += __shfl_xor(vd1, o, 64);
+    }
+    if (l == 0) {
+      if (okA) { a_src[(int64_t)hA * N + nA] = vs0; a_dst[(int64_t)hA * N + nA] = vd0; }
+      if (okB) { a_src[(int64_t)hB * N + nB] = vs1; a_dst[(int64_t)hB * N + nB] = vd1; }
+    }
+  }
+}
+
+// ---- backward of the scores, fused with the accumulation into dxp:
+//   dxp[n, h, :] += d_asrc[h][n] att_src[h, :] + d_adst[h][n] att_dst[h, :]
+//   d_att_src[h, c] = sum_n d_asrc[h][n] xp[n, h, c]      (d_att_dst likewise)
+// block b owns rows [b * rows_per, ..); thread t owns column quad t % fq and walks rows t / fq, + rpb, ..; block partials
+// in a fixed order, then one fp64 pass over the blocks (the layout of ceeg_colsum).
+constexpr int GAT_SB_THREADS = 256;
+constexpr int GAT_SB_MAX_BLOCKS = 1024;
+__global__ __launch_bounds__(GAT_SB_THREADS) void gat_scores_bwd_kernel(const float* __restrict__ xp, int64_t ldx,
+                                                                        const float* __restrict__ att_src, const float* __restrict__ att_dst,
+                                                                        const float* __restrict__ d_asrc, const float* __restrict__ d_adst,
+                                                                        int64_t N, int H, int C, float* dxp, int64_t ldd, int64_t rows_per,
+                                                                        float* __restrict__ part /* [grid][2][F] */) {
+  __shared__ float4 red[2][GAT_SB_THREADS];
+  const int F = H * C, fq = F / 4;
+  const int rpb = GAT_SB_THREADS / fq;
+  const int cq = threadIdx.x % fq, rr = threadIdx.x / fq;
+  const int h = 4 * cq / C;
+  const int64_t lo = (int64_t)blockIdx.x * rows_per;
+  const int64_t hi = lo + rows_per < N ? lo + rows_per : N;
+  float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
+  if (rr < rpb) {
+    const float4 ws = *reinterpret_cast<const float4*>(att_src + 4 * cq);
+    const float4 wd = *reinterpret_cast<const float4*>(att_dst + 4 * cq);
+    const float* ps = d_asrc + (int64_t)h * N;
+    const float* pd = d_adst + (int64_t)h * N;
+    int64_t n = lo + rr;
+    for (; n + rpb < hi; n += 2 * rpb) {  // two rows in flight
+      const int64_t m = n + rpb;
+      const float s0 = ps[n], d0 = pd[n], s1 = ps[m], d1 = pd[m];
+      const float4 x0 = *reinterpret_cast<const float4*>(xp + n * ldx + 4 * cq);
+      const float4 x1 = *reinterpret_cast<const float4*>(xp + m * ldx + 4 * cq);
+      float4 g0 = *reinterpret_cast<float4*>(dxp + n * ldd + 4 * cq);
+      float4 g1 = *reinterpret_cast<float4*>(dxp + m * ldd + 4 * cq);
+      g0.x += __fmaf_rn(s0, ws.x, d0 * wd.x); g0.y += __fmaf_rn(s0, ws.y, d0 * wd.y); g0.z += __fmaf_rn(s0, ws.z, d0 * wd.z); g0.w += __fmaf_rn(s0, ws.w, d0 * wd.w);
+      g1.x += __fmaf_rn(s1, ws.x, d1 * wd.x); g1.y += __fmaf_rn(s1, ws.y, d1 * wd.y); g1.z += __fmaf_rn(s1, ws.z, d1 * wd.z); g1.w += __fmaf_rn(s1, ws.w, d1 * wd.w);
+      *reinterpret_cast<float4*>(dxp + n * ldd + 4 * cq) = g0;
+      *reinterpret_cast<float4*>(dxp + m * ldd + 4 * cq) = g1;
+      as.x = __fmaf_rn(s0, x0.x, as.x); as.y = __fmaf_rn(s0, x0.y, as.y); as.z = __fmaf_rn(s0, x0.z, as.z); as.w = __fmaf_rn(s0, x0.w, as.w);
+      ad.x = __fmaf_rn(d0, x0.x, ad.x); ad.y = __fmaf_rn(d0, x0.y, ad.y); ad.z = __fmaf_rn(d0, x0.z, ad.z); ad.w = __fmaf_rn(d0, x0.w, ad.w);
+      as.x = __fmaf_rn(s1, x1.x, as.x); as.y = __fmaf_rn(s1, x1.y, as.y); as.z = __fmaf_rn(s1, x1.z, as.z); as.w = __fmaf_rn(s1, x1.w, as.w);
+      ad.x = __fmaf_rn(d1, x1.x, ad.x); ad.y = __fmaf_rn(d1, x1.y, ad.y); ad.z = __fmaf_rn(d1, x1.z, ad.z); ad.w = __fmaf_rn(d1, x1.w, ad.w);
+    }
+    if (n < hi) {
+      const float s0 = ps[n], d0 = pd[n];
+      const float4 x0 = *reinterpret_cast<const float4*>(xp + n * ldx + 4 * cq);
+      float4 g0 = *reinterpret_cast<float4*>(dxp + n * ldd + 4 * cq);
+      g0.x += __fmaf_rn(s0, ws.x, d0 * wd.x); g0.y += __fmaf_rn(s0, ws.y, d0 * wd.y); g0.z += __fmaf_rn(s0, ws.z, d0 * wd.z); g0.w += __fmaf_rn(s0, ws.w, d0 * wd.w);
+      *reinterpret_cast<float4*>(dxp + n * ldd + 4 * cq) = g0;
+      as.x = __fmaf_rn(s0, x0.x, as.x); as.y = __fmaf_rn(s0, x0.y, as.y); as.z = __fmaf_rn(s0, x0.z, as.z); as.w = __fmaf_rn(s0, x0.w, as.w);
+      ad.x = __fmaf_rn(d0, x0.x, ad.x); ad.y = __fmaf_rn(d0, x0.y, ad.y); ad.z = __fmaf_rn(d0, x0.z, ad.z); ad.w = __fmaf_rn(d0, x0.w, ad.w);
+    }
+  }
+  red[0][threadIdx.x] = as;
+  red[1][threadIdx.x] = ad;
+  __syncthreads();
+  if (rr == 0) {  // fixed order over the block's row groups
+    for (int k = 1; k < rpb; ++k) {
+      const float4 t = red[0][k * fq + cq], u = red[1][k * fq + cq];
+      as.x += t.x; as.y += t.y; as.z += t.z; as.w += t.w;
+      ad.x += u.x; ad.y += u.y; ad.z += u.z; ad.w += u.w;
+    }
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 2 * F + 4 * cq) = as;
+    *reinterpret_cast<float4*>(part + (size_t)blockIdx.x * 2 * F + F + 4 * cq) = ad;
+  }
+}
+
+// 16 columns (of the 2F) per block; 16 thread groups walk the block partials in a fixed interleave, fp64, then a fixed-order LDS sum
+__global__ __launch_bounds__(256) void gat_scores_bwd_finalize_kernel(const float* __restrict__ part, int nblk, int F2, int F,
+                                                                      float* __restrict__ d_att_src, float* __restrict__ d_att_dst) {
+  __shared__ double red[256];
+  const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + c;
+  double s = 0.0;
+  if (f < F2)
+    for (int b = grp; b < nblk; b += 16) s += (double)part[(size_t)b * F2 + f];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (grp == 0 && f < F2) {
+    for (int k = 1; k < 16; ++k) s += red[k * 16 + c];
+    if (f < F) d_att_src[f] = (float)s;
+    else d_att_dst[f - F] = (float)s;
+  }
+}
+
 int gat_lpr(int C) {
   const int need = (C + 3) / 4;
   int l = 1;
@@ -209,6 +334,63 @@ extern "C" int ceeg_segment_sum_perm(const int32_t* t_rowptr, const int32_t* t_p
   if (!t_rowptr || !v || !out || N <= 0) return CEEG_EINVAL;
   hipLaunchKernelGGL(segment_sum_perm_kernel, dim3(gat_blocks(N)), dim3(GAT_WAVES * 64), 0, static_cast<hipStream_t>(stream), t_rowptr,
                      t_perm, v, N, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_gat_scores_fwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, int64_t N, int H, int C,
+                                   float* a_src, float* a_dst, void* stream) {
+  if (!xp || !att_src || !att_dst || !a_src || !a_dst || N <= 0 || H <= 0) return CEEG_EINVAL;
+  if (C < 4 || (C % 4) != 0 || C > 256 || ldx < (int64_t)H * C || (ldx % 4) != 0) return CEEG_EUNSUPPORTED;
+  if (!ceeg_aligned(xp, 16) || !ceeg_aligned(att_src, 16) || !ceeg_aligned(att_dst, 16)) return CEEG_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int lpr = gat_lpr(C);
+  int64_t blocks = (N * H * lpr + 2 * 256 - 1) / (2 * 256);
+  if (blocks > 4 * GAT_MAX_BLOCKS) blocks = 4 * GAT_MAX_BLOCKS;
+  if (blocks < 1) blocks = 1;
+#define CEEG_GAT_CASE(L)                                                                                                                \
+  case L:                                                                                                                               \
+    hipLaunchKernelGGL(gat_scores_fwd_kernel<L>, dim3((unsigned)blocks), dim3(256), 0, st, xp, ldx, att_src, att_dst, N, H, C, a_src, a_dst); \
+    break;
+  switch (lpr) {
+    CEEG_GAT_CASE(1)
+    CEEG_GAT_CASE(2)
+    CEEG_GAT_CASE(4)
+    CEEG_GAT_CASE(8)
+    CEEG_GAT_CASE(16)
+    CEEG_GAT_CASE(32)
+    CEEG_GAT_CASE(64)
+    default: return CEEG_EUNSUPPORTED;
+  }
+#undef CEEG_GAT_CASE
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" size_t ceeg_gat_scores_bwd_ws_bytes(int64_t N, int H, int C) {
+  if (N <= 0 || H <= 0 || C <= 0) return 0;
+  return ceeg_ws_part((size_t)GAT_SB_MAX_BLOCKS * 2 * H * C, 4);
+}
+
+extern "C" int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, const float* d_asrc,
+                                   const float* d_adst, int64_t N, int H, int C, float* dxp, int64_t ldd, float* d_att_src,
+                                   float* d_att_dst, void* ws, size_t ws_bytes, void* stream) {
+  if (!xp || !att_src || !att_dst || !d_asrc || !d_adst || !dxp || !d_att_src || !d_att_dst || N <= 0 || H <= 0) return CEEG_EINVAL;
+  const int64_t F = (int64_t)H * C;
+  if (C < 4 || (C % 4) != 0 || C > 256 || F > 4 * GAT_SB_THREADS || ldx < F || ldd < F || (ldx % 4) != 0 || (ldd % 4) != 0) return CEEG_EUNSUPPORTED;
+  if (!ceeg_aligned(xp, 16) || !ceeg_aligned(dxp, 16) || !ceeg_aligned(att_src, 16) || !ceeg_aligned(att_dst, 16)) return CEEG_EINVAL;
+  if (ws_bytes < ceeg_gat_scores_bwd_ws_bytes(N, H, C) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int64_t nblk = (N + 255) / 256;
+  if (nblk > GAT_SB_MAX_BLOCKS) nblk = GAT_SB_MAX_BLOCKS;
+  const int64_t rows_per = (N + nblk - 1) / nblk;
+  nblk = (N + rows_per - 1) / rows_per;
+  float* part = static_cast<float*>(ws);
+  hipLaunchKernelGGL(gat_scores_bwd_kernel, dim3((unsigned)nblk), dim3(GAT_SB_THREADS), 0, st, xp, ldx, att_src, att_dst, d_asrc, d_adst, N, H,
+                     C, dxp, ldd, rows_per, part);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(gat_scores_bwd_finalize_kernel, dim3((unsigned)((2 * F + 15) / 16)), dim3(256), 0, st, part, (int)nblk, (int)(2 * F), (int)F,
+                     d_att_src, d_att_dst);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

@@ -812,30 +812,38 @@ class ConditionalVGAEVQ(nn.Module):
 # GATConv (the graph layer the reference actually instantiates: scripts/models.py:106)
 # ==================================================================================================
 class _GATAggregate(torch.autograd.Function):
-    """out[i, h] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * xp[j, h, :] over the CSR row of i (self-loops in).
-    Softmax weights: ceeg_gat_softmax_fwd; aggregation and its transpose: ceeg_spmm_csr; attention backward:
-    ceeg_gat_attn_bwd + ceeg_segment_sum_perm.  One pass per head over column slices (no copies)."""
+    """out[i, h] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * xp[j, h, :] over the CSR row of i (self-loops in),
+    with a_src[n,h] = <xp[n,h,:], att_src[h,:]>, a_dst likewise (PyG GATConv: (x_proj * att).sum(-1)).
+    Scores: ceeg_gat_scores_fwd (one pass over xp for both vectors and every head); softmax weights: ceeg_gat_softmax_fwd;
+    aggregation and its transpose: ceeg_spmm_csr, one pass per head over column slices (no copies); attention backward:
+    ceeg_gat_attn_bwd + ceeg_segment_sum_perm; the scores' backward lands in the same dxp (ceeg_gat_scores_bwd)."""
 
     @staticmethod
-    def forward(ctx, xp, a_src, a_dst, pair, heads, slope):
+    def forward(ctx, xp, att_src, att_dst, pair, heads, slope):
         _lib.require_cuda(xp)
         L = _lib.lib()
-        xp, a_src, a_dst = xp.contiguous(), a_src.t().contiguous(), a_dst.t().contiguous()  # a_*: [H, N]
+        xp = xp.contiguous()
         N, HC = xp.shape
         C = HC // heads
+        att_s, att_d = att_src.detach().reshape(-1).contiguous(), att_dst.detach().reshape(-1).contiguous()
+        a_src = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
+        a_dst = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
+        _lib.check(L.ceeg_gat_scores_fwd(xp.data_ptr(), xp.stride(0), att_s.data_ptr(), att_d.data_ptr(), N, heads, C, a_src.data_ptr(),
+                                         a_dst.data_ptr(), _lib.stream()), "ceeg_gat_scores_fwd")
         w = torch.empty(heads, max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
         out = torch.empty_like(xp)
         for h in range(heads):
             _lib.check(L.ceeg_gat_softmax_fwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), a_src[h].data_ptr(), a_dst[h].data_ptr(),
                                               N, pair.nnz, float(slope), w[h].data_ptr(), _lib.stream()), "ceeg_gat_softmax_fwd")
             _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, out=out[:, h * C:(h + 1) * C], max_row=pair.max_row)
-        ctx.save_for_backward(xp, a_src, a_dst, w)
+        ctx.save_for_backward(xp, a_src, a_dst, w, att_s, att_d)
         ctx.pair, ctx.heads, ctx.slope = pair, heads, float(slope)
+        ctx.att_shape = att_src.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
-        xp, a_src, a_dst, w = ctx.saved_tensors
+        xp, a_src, a_dst, w, att_s, att_d = ctx.saved_tensors
         pair, heads, slope = ctx.pair, ctx.heads, ctx.slope
         L = _lib.lib()
         g = g.contiguous()
@@ -853,7 +861,12 @@ class _GATAggregate(torch.autograd.Function):
                                            slope, dl.data_ptr(), d_adst[h].data_ptr(), _lib.stream()), "ceeg_gat_attn_bwd")
             _lib.check(L.ceeg_segment_sum_perm(pair.t_rowptr.data_ptr(), pair.t_perm.data_ptr(), dl.data_ptr(), N, d_asrc[h].data_ptr(),
                                                _lib.stream()), "ceeg_segment_sum_perm")
-        return dxp, d_asrc.t(), d_adst.t(), None, None, None
+        d_att = torch.empty(2, HC, dtype=torch.float32, device=xp.device)
+        ws = _lib.workspace(L.ceeg_gat_scores_bwd_ws_bytes(N, heads, C), xp.device)
+        _lib.check(L.ceeg_gat_scores_bwd(xp.data_ptr(), xp.stride(0), att_s.data_ptr(), att_d.data_ptr(), d_asrc.data_ptr(), d_adst.data_ptr(),
+                                         N, heads, C, dxp.data_ptr(), dxp.stride(0), d_att[0].data_ptr(), d_att[1].data_ptr(), ws.data_ptr(),
+                                         ws.numel(), _lib.stream()), "ceeg_gat_scores_bwd")
+        return dxp, d_att[0].view(ctx.att_shape), d_att[1].view(ctx.att_shape), None, None, None
 
 
 class GATConv(nn.Module):
@@ -888,10 +901,7 @@ class GATConv(nn.Module):
         pair = graph if isinstance(graph, CsrPair) else self.attention_graph(graph.edge_index if isinstance(graph, EventGraph) else graph, N)
         H, C = self.heads, self.out_channels
         xp = _Linear.apply(x, self.lin_src.weight, None, False)                     # [N, H*C]
-        xv = xp.view(N, H, C)
-        a_src = (xv * self.att_src).sum(dim=-1)                                     # [N, H]
-        a_dst = (xv * self.att_dst).sum(dim=-1)
-        out = _GATAggregate.apply(xp, a_src, a_dst, pair, H, self.negative_slope)
+        out = _GATAggregate.apply(xp, self.att_src, self.att_dst, pair, H, self.negative_slope)
         if not self.concat:
             out = out.view(N, H, C).mean(dim=1)
         return out if self.bias is None else out + self.bias

@@ -287,6 +287,18 @@ int ceeg_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const float*
 int ceeg_gat_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* w, const float* a_src,
                       const float* a_dst, const float* g, int64_t ldg, const float* xp, int64_t ldx, int64_t N,
                       int64_t nnz, int C, float slope, float* dl, float* d_adst, void* stream);
+/* Attention scores of every head in one pass over the projected features (PyG GATConv: (x_proj * att).sum(-1)):
+ *   a_src[h*N + n] = <xp[n, h*C : (h+1)*C], att_src[h*C : (h+1)*C]>,  a_dst likewise.     xp [N, ldx], att_* [H*C].
+ * Their backward, fused with the accumulation into the gradient of xp (dxp holds the aggregation's share on entry):
+ *   dxp[n, h, :] += d_asrc[h*N+n] att_src[h, :] + d_adst[h*N+n] att_dst[h, :]
+ *   d_att_src[h*C + c] = sum_n d_asrc[h*N+n] xp[n, h*C + c]   (d_att_dst likewise; block partials in a fixed order, fp64
+ *   across blocks: deterministic).  C % 4 == 0, C <= 256, H*C <= 1024. */
+int ceeg_gat_scores_fwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, int64_t N, int H, int C,
+                        float* a_src, float* a_dst, void* stream);
+size_t ceeg_gat_scores_bwd_ws_bytes(int64_t N, int H, int C);
+int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, const float* d_asrc,
+                        const float* d_adst, int64_t N, int H, int C, float* dxp, int64_t ldd, float* d_att_src,
+                        float* d_att_dst, void* ws, size_t ws_bytes, void* stream);
 /* out[r] = sum_{q in [t_rowptr[r], t_rowptr[r+1])} v[t_perm[q]]  (t_perm NULL: v[q]); fixed-order wave sums. */
 int ceeg_segment_sum_perm(const int32_t* t_rowptr, const int32_t* t_perm, const float* v, int64_t N,
                           float* out, void* stream);

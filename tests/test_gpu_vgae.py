@@ -325,8 +325,15 @@ def test_gatconv_fwd_bwd_vs_oracle(N, E, Fi, C, H, concat):
     _close(b.grad, a.grad, rtol=1e-3, atol_rel=1e-4)
     for name, p in conv.named_parameters():
         _close(p.grad, dict(ref.named_parameters())[name].grad, rtol=1e-3, atol_rel=1e-4)
+    grads = {name: p.grad.clone() for name, p in conv.named_parameters()}
+    bg = b.grad.clone()
+    conv.zero_grad(set_to_none=True)
+    b.grad = None
     out2 = conv(b, ei.cuda())
-    assert torch.equal(out, out2)
+    (out2 * r.cuda()).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(bg, b.grad)  # no atomics anywhere: bitwise run-to-run
+    for name, p in conv.named_parameters():
+        assert torch.equal(p.grad, grads[name]), name
 
 
 def test_global_attention_and_graph_layernorm_vs_oracle():
