@@ -55,6 +55,8 @@ SIGNATURES = {
     "ceeg_gat_softmax_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f32, _vp, _vp]),
     "ceeg_gat_attn_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_f32, _vp, _vp, _vp]),
     "ceeg_segment_sum_perm": (_c_int, [_vp, _vp, _vp, _c_i64, _vp, _vp]),
+    "ceeg_segment_sum_items_ws_bytes": (_c_sz, [_c_i64]),
+    "ceeg_segment_sum_perm_items": (_c_int, [_vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),
     "ceeg_gat_scores_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
     "ceeg_gat_scores_bwd_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int]),
     "ceeg_gat_scores_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _c_i64, _vp, _vp, _vp, _c_sz, _vp]),

@@ -816,7 +816,7 @@ class _GATAggregate(torch.autograd.Function):
     with a_src[n,h] = <xp[n,h,:], att_src[h,:]>, a_dst likewise (PyG GATConv: (x_proj * att).sum(-1)).
     Scores: ceeg_gat_scores_fwd (one pass over xp for both vectors and every head); softmax weights: ceeg_gat_softmax_fwd;
     aggregation and its transpose: ceeg_spmm_csr, one pass per head over column slices (no copies); attention backward:
-    ceeg_gat_attn_bwd + ceeg_segment_sum_perm; the scores' backward lands in the same dxp (ceeg_gat_scores_bwd)."""
+    ceeg_gat_attn_bwd + ceeg_segment_sum_perm_items; the scores' backward lands in the same dxp (ceeg_gat_scores_bwd)."""
 
     @staticmethod
     def forward(ctx, xp, att_src, att_dst, pair, heads, slope):
@@ -853,14 +853,19 @@ class _GATAggregate(torch.autograd.Function):
         d_asrc = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
         d_adst = torch.empty(heads, N, dtype=torch.float32, device=xp.device)
         dl = torch.empty(max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
+        lt = pair.long_items(True)  # hub sources: their scalar segment sums go by pieces
+        n_lt = 0 if lt is None else lt.shape[0]
+        chunk = int(L.ceeg_decoder_codes_chunk())
+        ws_seg = _lib.workspace(L.ceeg_segment_sum_items_ws_bytes(n_lt), xp.device) if n_lt else None
         for h in range(heads):
             gs, xs = g[:, h * C:(h + 1) * C], xp[:, h * C:(h + 1) * C]
             _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, gs, N, out=dxp[:, h * C:(h + 1) * C], max_row=pair.max_trow)
             _lib.check(L.ceeg_gat_attn_bwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), w[h].data_ptr(), a_src[h].data_ptr(),
                                            a_dst[h].data_ptr(), gs.data_ptr(), gs.stride(0), xs.data_ptr(), xs.stride(0), N, pair.nnz, C,
                                            slope, dl.data_ptr(), d_adst[h].data_ptr(), _lib.stream()), "ceeg_gat_attn_bwd")
-            _lib.check(L.ceeg_segment_sum_perm(pair.t_rowptr.data_ptr(), pair.t_perm.data_ptr(), dl.data_ptr(), N, d_asrc[h].data_ptr(),
-                                               _lib.stream()), "ceeg_segment_sum_perm")
+            _lib.check(L.ceeg_segment_sum_perm_items(pair.t_rowptr.data_ptr(), pair.t_perm.data_ptr(), dl.data_ptr(), N, _lib.ptr(lt), n_lt,
+                                                     chunk, d_asrc[h].data_ptr(), _lib.ptr(ws_seg), 0 if ws_seg is None else ws_seg.numel(),
+                                                     _lib.stream()), "ceeg_segment_sum_perm_items")
         d_att = torch.empty(2, HC, dtype=torch.float32, device=xp.device)
         ws = _lib.workspace(L.ceeg_gat_scores_bwd_ws_bytes(N, heads, C), xp.device)
         _lib.check(L.ceeg_gat_scores_bwd(xp.data_ptr(), xp.stride(0), att_s.data_ptr(), att_d.data_ptr(), d_asrc.data_ptr(), d_adst.data_ptr(),

@@ -302,6 +302,12 @@ int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* att_src, cons
 /* out[r] = sum_{q in [t_rowptr[r], t_rowptr[r+1])} v[t_perm[q]]  (t_perm NULL: v[q]); fixed-order wave sums. */
 int ceeg_segment_sum_perm(const int32_t* t_rowptr, const int32_t* t_perm, const float* v, int64_t N,
                           float* out, void* stream);
+/* The same sums with the rows longer than `chunk` entries taken from the graph's static piece list (items [n][4] int32 =
+ * (lo, hi, -, row), rows and pieces ascending, every row longer than chunk listed completely - CsrPair.long_items): one wave
+ * per piece, pieces of a row added in list order.  A hub source no longer serialises on one wave. */
+size_t ceeg_segment_sum_items_ws_bytes(int64_t n_items);
+int ceeg_segment_sum_perm_items(const int32_t* t_rowptr, const int32_t* t_perm, const float* v, int64_t N, const int32_t* items,
+                                int64_t n_items, int chunk, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected

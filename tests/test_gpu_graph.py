@@ -187,3 +187,35 @@ def test_spmm_piece_list_equals_row_scan():
                 b = _spmm(rp, col, val, None, x, N, max_row=mr, items=p.long_items(tr))
                 c = _spmm(rp, col, val, None, x, N)  # no hint at all
                 assert torch.equal(a, b) and torch.equal(a, c)
+
+
+def test_segment_sum_piece_list_equals_row_walk():
+    """ceeg_segment_sum_perm_items (hub rows by pieces of the graph's static list) against ceeg_segment_sum_perm (one wave
+    per row) and an fp64 scatter-add: with a permutation, without one, with and without hub rows; deterministic."""
+    from causal_eeg_vae_amd import EventGraph, _lib
+    from causal_eeg_vae_amd.synth import synth_event_graph
+    L = _lib.lib()
+    chunk = int(L.ceeg_decoder_codes_chunk())
+    for N, E in ((50_000, 800_000), (3_000, 20_000)):
+        p = EventGraph(synth_event_graph(N, E, seed=9, device="cuda"), N).gcn
+        items = p.long_items(True)
+        if N == 50_000:
+            assert items is not None and p.max_trow > chunk
+        n_items = 0 if items is None else items.shape[0]
+        v = torch.randn(p.nnz, device="cuda")
+        ws = _lib.workspace(L.ceeg_segment_sum_items_ws_bytes(n_items), v.device)
+        for perm in (p.t_perm, None):
+            a = torch.empty(N, device="cuda")
+            b = torch.full((N,), float("nan"), device="cuda")
+            b2 = torch.full((N,), float("nan"), device="cuda")
+            _lib.check(L.ceeg_segment_sum_perm(p.t_rowptr.data_ptr(), _lib.ptr(perm), v.data_ptr(), N, a.data_ptr(), _lib.stream()), "plain")
+            for out in (b, b2):
+                _lib.check(L.ceeg_segment_sum_perm_items(p.t_rowptr.data_ptr(), _lib.ptr(perm), v.data_ptr(), N, _lib.ptr(items), n_items, chunk,
+                                                         out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "items")
+            assert torch.equal(b, b2)
+            rows = torch.repeat_interleave(torch.arange(N, device="cuda"), (p.t_rowptr[1:] - p.t_rowptr[:-1]).long())
+            src = v if perm is None else v[perm.long()]
+            ref = torch.zeros(N, dtype=torch.float64, device="cuda").index_add_(0, rows, src.double())
+            mag = torch.zeros(N, dtype=torch.float64, device="cuda").index_add_(0, rows, src.double().abs())
+            assert float(((b.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
+            assert float(((a.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
