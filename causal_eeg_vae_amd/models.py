@@ -832,10 +832,12 @@ class _GATAggregate(torch.autograd.Function):
                                          a_dst.data_ptr(), _lib.stream()), "ceeg_gat_scores_fwd")
         w = torch.empty(heads, max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
         out = torch.empty_like(xp)
+        li = pair.long_items(False)
         for h in range(heads):
             _lib.check(L.ceeg_gat_softmax_fwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), a_src[h].data_ptr(), a_dst[h].data_ptr(),
                                               N, pair.nnz, float(slope), w[h].data_ptr(), _lib.stream()), "ceeg_gat_softmax_fwd")
-            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, out=out[:, h * C:(h + 1) * C], max_row=pair.max_row)
+            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, out=out[:, h * C:(h + 1) * C], max_row=pair.max_row,
+                  items=li)
         ctx.save_for_backward(xp, a_src, a_dst, w, att_s, att_d)
         ctx.pair, ctx.heads, ctx.slope = pair, heads, float(slope)
         ctx.att_shape = att_src.shape
@@ -859,7 +861,7 @@ class _GATAggregate(torch.autograd.Function):
         ws_seg = _lib.workspace(L.ceeg_segment_sum_items_ws_bytes(n_lt), xp.device) if n_lt else None
         for h in range(heads):
             gs, xs = g[:, h * C:(h + 1) * C], xp[:, h * C:(h + 1) * C]
-            _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, gs, N, out=dxp[:, h * C:(h + 1) * C], max_row=pair.max_trow)
+            _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, gs, N, out=dxp[:, h * C:(h + 1) * C], max_row=pair.max_trow, items=lt)
             _lib.check(L.ceeg_gat_attn_bwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), w[h].data_ptr(), a_src[h].data_ptr(),
                                            a_dst[h].data_ptr(), gs.data_ptr(), gs.stride(0), xs.data_ptr(), xs.stride(0), N, pair.nnz, C,
                                            slope, dl.data_ptr(), d_adst[h].data_ptr(), _lib.stream()), "ceeg_gat_attn_bwd")
