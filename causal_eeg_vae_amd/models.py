@@ -819,7 +819,8 @@ class _GATAggregate(torch.autograd.Function):
     ceeg_gat_attn_bwd + ceeg_segment_sum_perm_items; the scores' backward lands in the same dxp (ceeg_gat_scores_bwd)."""
 
     @staticmethod
-    def forward(ctx, xp, att_src, att_dst, pair, heads, slope):
+    def forward(ctx, xp, att_src, att_dst, bias, pair, heads, slope):
+        """bias: None or the [heads * C] output bias of the concatenating layer, added in the aggregation's epilogue."""
         _lib.require_cuda(xp)
         L = _lib.lib()
         xp = xp.contiguous()
@@ -833,11 +834,13 @@ class _GATAggregate(torch.autograd.Function):
         w = torch.empty(heads, max(pair.nnz, 1), dtype=torch.float32, device=xp.device)
         out = torch.empty_like(xp)
         li = pair.long_items(False)
+        bias_v = None if bias is None else bias.detach().contiguous()
+        ctx.has_bias = bias is not None
         for h in range(heads):
             _lib.check(L.ceeg_gat_softmax_fwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), a_src[h].data_ptr(), a_dst[h].data_ptr(),
                                               N, pair.nnz, float(slope), w[h].data_ptr(), _lib.stream()), "ceeg_gat_softmax_fwd")
-            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, out=out[:, h * C:(h + 1) * C], max_row=pair.max_row,
-                  items=li)
+            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, bias=None if bias_v is None else bias_v[h * C:(h + 1) * C],
+                  out=out[:, h * C:(h + 1) * C], max_row=pair.max_row, items=li)
         ctx.save_for_backward(xp, a_src, a_dst, w, att_s, att_d)
         ctx.pair, ctx.heads, ctx.slope = pair, heads, float(slope)
         ctx.att_shape = att_src.shape
@@ -873,7 +876,8 @@ class _GATAggregate(torch.autograd.Function):
         _lib.check(L.ceeg_gat_scores_bwd(xp.data_ptr(), xp.stride(0), att_s.data_ptr(), att_d.data_ptr(), d_asrc.data_ptr(), d_adst.data_ptr(),
                                          N, heads, C, dxp.data_ptr(), dxp.stride(0), d_att[0].data_ptr(), d_att[1].data_ptr(), ws.data_ptr(),
                                          ws.numel(), _lib.stream()), "ceeg_gat_scores_bwd")
-        return dxp, d_att[0].view(ctx.att_shape), d_att[1].view(ctx.att_shape), None, None, None
+        d_bias = _colsum(g) if ctx.has_bias else None
+        return dxp, d_att[0].view(ctx.att_shape), d_att[1].view(ctx.att_shape), d_bias, None, None, None
 
 
 class GATConv(nn.Module):
@@ -908,7 +912,8 @@ class GATConv(nn.Module):
         pair = graph if isinstance(graph, CsrPair) else self.attention_graph(graph.edge_index if isinstance(graph, EventGraph) else graph, N)
         H, C = self.heads, self.out_channels
         xp = _Linear.apply(x, self.lin_src.weight, None, False)                     # [N, H*C]
-        out = _GATAggregate.apply(xp, self.att_src, self.att_dst, pair, H, self.negative_slope)
-        if not self.concat:
-            out = out.view(N, H, C).mean(dim=1)
+        if self.concat:  # the bias rides in the aggregation's epilogue
+            return _GATAggregate.apply(xp, self.att_src, self.att_dst, self.bias, pair, H, self.negative_slope)
+        out = _GATAggregate.apply(xp, self.att_src, self.att_dst, None, pair, H, self.negative_slope)
+        out = out.view(N, H, C).mean(dim=1)
         return out if self.bias is None else out + self.bias
