@@ -219,3 +219,35 @@ def test_segment_sum_piece_list_equals_row_walk():
             mag = torch.zeros(N, dtype=torch.float64, device="cuda").index_add_(0, rows, src.double().abs())
             assert float(((b.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
             assert float(((a.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
+
+
+def test_gat_entry_points_reject_bad_arguments():
+    """The GAT score / segment-sum entry points return error codes (no launch) for shapes they do not implement, a short
+    workspace, or missing pointers - the same loud-failure rule as the rest of the C-ABI."""
+    from causal_eeg_vae_amd import _lib
+    L = _lib.lib()
+    N, H, C = 100, 2, 8
+    xp = torch.randn(N, H * C, device="cuda")
+    att = torch.randn(H * C, device="cuda")
+    a = torch.empty(H, N, device="cuda")
+    st = _lib.stream()
+    assert L.ceeg_gat_scores_fwd(xp.data_ptr(), xp.stride(0), att.data_ptr(), att.data_ptr(), N, H, C, a.data_ptr(), a.data_ptr(), st) == 0
+    assert L.ceeg_gat_scores_fwd(xp.data_ptr(), xp.stride(0), att.data_ptr(), att.data_ptr(), N, H, 6, a.data_ptr(), a.data_ptr(), st) < 0   # C % 4
+    assert L.ceeg_gat_scores_fwd(xp.data_ptr(), 8, att.data_ptr(), att.data_ptr(), N, H, C, a.data_ptr(), a.data_ptr(), st) < 0            # ld < H*C
+    assert L.ceeg_gat_scores_fwd(None, xp.stride(0), att.data_ptr(), att.data_ptr(), N, H, C, a.data_ptr(), a.data_ptr(), st) < 0
+    d = torch.empty(2, H * C, device="cuda")
+    ws = _lib.workspace(L.ceeg_gat_scores_bwd_ws_bytes(N, H, C), xp.device)
+    dxp = torch.zeros_like(xp)
+    args = (xp.data_ptr(), xp.stride(0), att.data_ptr(), att.data_ptr(), a.data_ptr(), a.data_ptr(), N, H, C, dxp.data_ptr(), dxp.stride(0),
+            d[0].data_ptr(), d[1].data_ptr())
+    assert L.ceeg_gat_scores_bwd(*args, ws.data_ptr(), 16, st) < 0                       # workspace too small
+    assert L.ceeg_gat_scores_bwd(*args, None, ws.numel(), st) < 0
+    assert L.ceeg_gat_scores_bwd(*args[:8], 260, *args[9:], ws.data_ptr(), ws.numel(), st) < 0  # C > 256
+    rp = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
+    out = torch.empty(N, device="cuda")
+    v = torch.zeros(1, device="cuda")
+    items = torch.zeros(1, 4, dtype=torch.int32, device="cuda")
+    assert L.ceeg_segment_sum_perm_items(rp.data_ptr(), None, v.data_ptr(), N, items.data_ptr(), 1, 256, out.data_ptr(), None, 0, st) < 0  # no workspace
+    assert L.ceeg_segment_sum_perm_items(rp.data_ptr(), None, v.data_ptr(), N, None, 0, 256, out.data_ptr(), None, 0, st) == 0
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0
