@@ -155,9 +155,11 @@ def main():
         torch.manual_seed(0)
         conv = GATConv(args.in_dim, 2 * args.latent, heads=args.gat_heads).to(dev)
 
+        gout = torch.ones(N, 2 * args.latent * args.gat_heads, device=dev)  # the incoming gradient, allocated once
+
         def once():
             out = conv(x, graph)
-            out.backward(torch.ones_like(out))
+            out.backward(gout)
             x.grad = None
             conv.zero_grad(set_to_none=True)
 

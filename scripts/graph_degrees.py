@@ -1,7 +1,12 @@
 """Degree statistics of the bench graph (attention CSR): longest rows of the CSR and of its transpose."""
+import os
+import sys
+
 import torch
-from causal_eeg_vae_amd import GATConv
-from causal_eeg_vae_amd.synth import synth_event_graph
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from causal_eeg_vae_amd import GATConv  # noqa: E402
+from causal_eeg_vae_amd.synth import synth_event_graph  # noqa: E402
 
 ei = synth_event_graph(1_000_000, 16_000_000, seed=1000, device="cuda")
 pair = GATConv.attention_graph(ei, 1_000_000)
