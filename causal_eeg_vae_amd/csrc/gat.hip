@@ -103,7 +103,7 @@ template <int CTRL>
 __device__ __forceinline__ float gat_dpp(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, false)); }
 
 __device__ __forceinline__ float gat_batch_dots64(const float* __restrict__ xp, int64_t ldx, int my_c, int n, int lane, bool fl_ok,
-                                                  const float4& gr) {
+                                                  const float4& gr, const float* __restrict__ grow, int C) {
   float mine = 0.f;
   const int rounds = n < 8 ? n : 8;  // round t: entries 8k + t, k = 0..7 (those below n); measured faster than entries 8t + k
   for (int t = 0; t < rounds; ++t) {   // (2.14 vs 2.33 ms on the 1M/16M graph) although a 17-entry row then takes 8 rounds of <= 3 gathers
@@ -115,6 +115,21 @@ __device__ __forceinline__ float gat_batch_dots64(const float* __restrict__ xp, 
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < n && fl_ok) x = *reinterpret_cast<const float4*>(xp + (int64_t)c * ldx + 4 * lane);
       d[k] = gat_dot4(x, gr);
+    }
+    // heads wider than 256 columns (the reference's 2048-wide layers): further 256-column chunks, the chunk of g[row]
+    // fetched once per round and shared by the 8 entries
+    for (int c0 = 256; c0 < C; c0 += 256) {
+      const bool ok = c0 + 4 * lane < C;
+      float4 gc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) gc = *reinterpret_cast<const float4*>(grow + c0 + 4 * lane);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int j = 8 * k + t;
+        const int c = __builtin_amdgcn_readlane(my_c, j);
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < n && ok) x = *reinterpret_cast<const float4*>(xp + (int64_t)c * ldx + c0 + 4 * lane);
+        d[k] += gat_dot4(x, gc);
+      }
     }
     // the lanes with (b5, b4, b3) = k end up holding dot k - the group lane 8k + t lives in: no final shuffle
     const float a0 = gat_swap_add32(d[0], d[4]), a1 = gat_swap_add32(d[1], d[5]);
@@ -132,8 +147,9 @@ __device__ __forceinline__ float gat_batch_dots64(const float* __restrict__ xp, 
 }
 
 template <int LPR>
-__device__ __forceinline__ float gat_dots(const float* __restrict__ xp, int64_t ldx, int my_c, int n, int lane, bool fl_ok, const float4& gr) {
-  if constexpr (LPR == 64) return gat_batch_dots64(xp, ldx, my_c, n, lane, fl_ok, gr);
+__device__ __forceinline__ float gat_dots(const float* __restrict__ xp, int64_t ldx, int my_c, int n, int lane, bool fl_ok, const float4& gr,
+                                          const float* __restrict__ grow, int C) {
+  if constexpr (LPR == 64) return gat_batch_dots64(xp, ldx, my_c, n, lane, fl_ok, gr, grow, C);
   else return gat_batch_dots<LPR>(xp, ldx, my_c, n, lane, fl_ok, gr);
 }
 
@@ -162,7 +178,7 @@ __global__ __launch_bounds__(GAT_WAVES * 64) void gat_attn_bwd_kernel(
     for (int base = p_lo; base < p_hi; base += 64) {
       const int n = p_hi - base < 64 ? p_hi - base : 64;
       const int my_c = lane < n ? col[base + lane] : 0;
-      const float dw = gat_dots<LPR>(xp, ldx, my_c, n, lane, fl_ok, gr);
+      const float dw = gat_dots<LPR>(xp, ldx, my_c, n, lane, fl_ok, gr, g + r * ldg, C);
       if (base == p_lo) dw0 = dw;
       else if (lane < n) dl[base + lane] = dw;  // parked in the output slot: pass 2 reads it back instead of gathering the rows again
       if (lane < n) s = __fmaf_rn(w[base + lane], dw, s);
@@ -244,23 +260,22 @@ __global__ __launch_bounds__(256) void gat_scores_fwd_kernel(const float* __rest
   const int64_t grp = ((int64_t)blockIdx.x * 256 + threadIdx.x) / LPR;
   const int64_t ngrp = (int64_t)gridDim.x * 256 / LPR;
   const int64_t items = N * H;
-  const bool live = 4 * l < C;
   for (int64_t it0 = grp; it0 < items + ngrp; it0 += 2 * ngrp) {  // two items in flight per group
     const int64_t itA = it0, itB = it0 + ngrp;
     const bool okA = itA < items, okB = itB < items;
     if (!okA && !okB) break;
     const int64_t nA = okA ? itA / H : 0, nB = okB ? itB / H : 0;
     const int hA = okA ? (int)(itA - nA * H) : 0, hB = okB ? (int)(itB - nB * H) : 0;
-    float4 xA = make_float4(0.f, 0.f, 0.f, 0.f), xB = xA, sA = xA, dA = xA, sB = xA, dB = xA;
-    if (live) {
-      xA = *reinterpret_cast<const float4*>(xp + nA * ldx + hA * C + 4 * l);
-      xB = *reinterpret_cast<const float4*>(xp + nB * ldx + hB * C + 4 * l);
-      sA = *reinterpret_cast<const float4*>(att_src + hA * C + 4 * l);
-      dA = *reinterpret_cast<const float4*>(att_dst + hA * C + 4 * l);
-      sB = *reinterpret_cast<const float4*>(att_src + hB * C + 4 * l);
-      dB = *reinterpret_cast<const float4*>(att_dst + hB * C + 4 * l);
+    float vs0 = 0.f, vd0 = 0.f, vs1 = 0.f, vd1 = 0.f;
+    for (int c = 4 * l; c < C; c += 4 * LPR) {  // one trip for C <= 256; wider heads in chunks of 4 LPR = 256 columns
+      const float4 xA = *reinterpret_cast<const float4*>(xp + nA * ldx + hA * C + c);
+      const float4 xB = *reinterpret_cast<const float4*>(xp + nB * ldx + hB * C + c);
+      const float4 sA = *reinterpret_cast<const float4*>(att_src + hA * C + c);
+      const float4 dA = *reinterpret_cast<const float4*>(att_dst + hA * C + c);
+      const float4 sB = *reinterpret_cast<const float4*>(att_src + hB * C + c);
+      const float4 dB = *reinterpret_cast<const float4*>(att_dst + hB * C + c);
+      vs0 += gat_dot4(xA, sA); vd0 += gat_dot4(xA, dA); vs1 += gat_dot4(xB, sB); vd1 += gat_dot4(xB, dB);
     }
-    float vs0 = gat_dot4(xA, sA), vd0 = gat_dot4(xA, dA), vs1 = gat_dot4(xB, sB), vd1 = gat_dot4(xB, dB);
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) {
       vs0 += __shfl_xor(vs0, o, 64);
@@ -285,13 +300,14 @@ constexpr int GAT_SB_MAX_BLOCKS = 1024;
 __global__ __launch_bounds__(GAT_SB_THREADS) void gat_scores_bwd_kernel(const float* __restrict__ xp, int64_t ldx,
                                                                         const float* __restrict__ att_src, const float* __restrict__ att_dst,
                                                                         const float* __restrict__ d_asrc, const float* __restrict__ d_adst,
-                                                                        int64_t N, int H, int C, float* dxp, int64_t ldd, int64_t rows_per,
-                                                                        float* __restrict__ part /* [grid][2][F] */) {
+                                                                        int64_t N, int F, int col_off, int C, float* dxp, int64_t ldd,
+                                                                        int64_t rows_per, float* __restrict__ part /* [grid][2][F] */) {
+  // F columns starting at column col_off of the H * C wide matrices (xp, dxp, att_* already point at col_off)
   __shared__ float4 red[2][GAT_SB_THREADS];
-  const int F = H * C, fq = F / 4;
+  const int fq = F / 4;
   const int rpb = GAT_SB_THREADS / fq;
   const int cq = threadIdx.x % fq, rr = threadIdx.x / fq;
-  const int h = 4 * cq / C;
+  const int h = (col_off + 4 * cq) / C;
   const int64_t lo = (int64_t)blockIdx.x * rows_per;
   const int64_t hi = lo + rows_per < N ? lo + rows_per : N;
   float4 as = make_float4(0.f, 0.f, 0.f, 0.f), ad = as;
@@ -359,10 +375,10 @@ __global__ __launch_bounds__(256) void gat_scores_bwd_finalize_kernel(const floa
   }
 }
 
-int gat_lpr(int C) {
+int gat_lpr(int C) {  // lanes per row: next power of two >= C / 4, at most the wave (wider rows go in 256-column chunks)
   const int need = (C + 3) / 4;
   int l = 1;
-  while (l < need) l <<= 1;
+  while (l < need && l < 64) l <<= 1;
   return l;
 }
 
@@ -382,7 +398,7 @@ extern "C" int ceeg_gat_attn_bwd(const int32_t* rowptr, const int32_t* col, cons
                                  const float* a_dst, const float* g, int64_t ldg, const float* xp, int64_t ldx, int64_t N,
                                  int64_t nnz, int C, float slope, float* dl, float* d_adst, void* stream) {
   if (!rowptr || !a_src || !a_dst || !g || !xp || !d_adst || N <= 0 || nnz < 0 || (nnz > 0 && (!col || !w || !dl))) return CEEG_EINVAL;
-  if (C < 4 || (C % 4) != 0 || C > 256 || ldg < C || ldx < C || (ldg % 4) != 0 || (ldx % 4) != 0) return CEEG_EUNSUPPORTED;
+  if (C < 4 || (C % 4) != 0 || C > 2048 || ldg < C || ldx < C || (ldg % 4) != 0 || (ldx % 4) != 0) return CEEG_EUNSUPPORTED;
   if (N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(g, 16) || !ceeg_aligned(xp, 16)) return CEEG_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -442,7 +458,7 @@ extern "C" int ceeg_segment_sum_perm_items(const int32_t* t_rowptr, const int32_
 extern "C" int ceeg_gat_scores_fwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, int64_t N, int H, int C,
                                    float* a_src, float* a_dst, void* stream) {
   if (!xp || !att_src || !att_dst || !a_src || !a_dst || N <= 0 || H <= 0) return CEEG_EINVAL;
-  if (C < 4 || (C % 4) != 0 || C > 256 || ldx < (int64_t)H * C || (ldx % 4) != 0) return CEEG_EUNSUPPORTED;
+  if (C < 4 || (C % 4) != 0 || C > 2048 || ldx < (int64_t)H * C || (ldx % 4) != 0) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(xp, 16) || !ceeg_aligned(att_src, 16) || !ceeg_aligned(att_dst, 16)) return CEEG_EINVAL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int lpr = gat_lpr(C);
@@ -470,7 +486,8 @@ extern "C" int ceeg_gat_scores_fwd(const float* xp, int64_t ldx, const float* at
 
 extern "C" size_t ceeg_gat_scores_bwd_ws_bytes(int64_t N, int H, int C) {
   if (N <= 0 || H <= 0 || C <= 0) return 0;
-  return ceeg_ws_part((size_t)GAT_SB_MAX_BLOCKS * 2 * H * C, 4);
+  const size_t F = (size_t)H * C;
+  return ceeg_ws_part((size_t)GAT_SB_MAX_BLOCKS * 2 * (F < 4 * GAT_SB_THREADS ? F : 4 * GAT_SB_THREADS), 4);
 }
 
 extern "C" int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, const float* d_asrc,
@@ -478,7 +495,7 @@ extern "C" int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* at
                                    float* d_att_dst, void* ws, size_t ws_bytes, void* stream) {
   if (!xp || !att_src || !att_dst || !d_asrc || !d_adst || !dxp || !d_att_src || !d_att_dst || N <= 0 || H <= 0) return CEEG_EINVAL;
   const int64_t F = (int64_t)H * C;
-  if (C < 4 || (C % 4) != 0 || C > 256 || F > 4 * GAT_SB_THREADS || ldx < F || ldd < F || (ldx % 4) != 0 || (ldd % 4) != 0) return CEEG_EUNSUPPORTED;
+  if (C < 4 || (C % 4) != 0 || C > 2048 || F > 16384 || ldx < F || ldd < F || (ldx % 4) != 0 || (ldd % 4) != 0) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(xp, 16) || !ceeg_aligned(dxp, 16) || !ceeg_aligned(att_src, 16) || !ceeg_aligned(att_dst, 16)) return CEEG_EINVAL;
   if (ws_bytes < ceeg_gat_scores_bwd_ws_bytes(N, H, C) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -487,11 +504,14 @@ extern "C" int ceeg_gat_scores_bwd(const float* xp, int64_t ldx, const float* at
   const int64_t rows_per = (N + nblk - 1) / nblk;
   nblk = (N + rows_per - 1) / rows_per;
   float* part = static_cast<float*>(ws);
-  hipLaunchKernelGGL(gat_scores_bwd_kernel, dim3((unsigned)nblk), dim3(GAT_SB_THREADS), 0, st, xp, ldx, att_src, att_dst, d_asrc, d_adst, N, H,
-                     C, dxp, ldd, rows_per, part);
-  CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gat_scores_bwd_finalize_kernel, dim3((unsigned)((2 * F + 15) / 16)), dim3(256), 0, st, part, (int)nblk, (int)(2 * F), (int)F,
-                     d_att_src, d_att_dst);
-  CEEG_CHECK_LAUNCH();
+  for (int64_t off = 0; off < F; off += 4 * GAT_SB_THREADS) {  // column blocks of <= 1024 (one column quad per thread); stream-ordered reuse of part
+    const int fb = (int)(F - off < 4 * GAT_SB_THREADS ? F - off : 4 * GAT_SB_THREADS);
+    hipLaunchKernelGGL(gat_scores_bwd_kernel, dim3((unsigned)nblk), dim3(GAT_SB_THREADS), 0, st, xp + off, ldx, att_src + off, att_dst + off,
+                       d_asrc, d_adst, N, fb, (int)off, C, dxp + off, ldd, rows_per, part);
+    CEEG_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gat_scores_bwd_finalize_kernel, dim3((unsigned)((2 * fb + 15) / 16)), dim3(256), 0, st, part, (int)nblk, 2 * fb, fb,
+                       d_att_src + off, d_att_dst + off);
+    CEEG_CHECK_LAUNCH();
+  }
   return CEEG_OK;
 }

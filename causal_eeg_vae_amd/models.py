@@ -811,6 +811,9 @@ class ConditionalVGAEVQ(nn.Module):
 # ==================================================================================================
 # GATConv (the graph layer the reference actually instantiates: scripts/models.py:106)
 # ==================================================================================================
+_SPMM_MAX_F = 1024  # widest feature slice of one ceeg_spmm_csr call (include/ceeg.h)
+
+
 class _GATAggregate(torch.autograd.Function):
     """out[i, h] = sum_j softmax_j(leaky_relu(a_src[j,h] + a_dst[i,h])) * xp[j, h, :] over the CSR row of i (self-loops in),
     with a_src[n,h] = <xp[n,h,:], att_src[h,:]>, a_dst likewise (PyG GATConv: (x_proj * att).sum(-1)).
@@ -839,8 +842,10 @@ class _GATAggregate(torch.autograd.Function):
         for h in range(heads):
             _lib.check(L.ceeg_gat_softmax_fwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), a_src[h].data_ptr(), a_dst[h].data_ptr(),
                                               N, pair.nnz, float(slope), w[h].data_ptr(), _lib.stream()), "ceeg_gat_softmax_fwd")
-            _spmm(pair.rowptr, pair.col, w[h], None, xp[:, h * C:(h + 1) * C], N, bias=None if bias_v is None else bias_v[h * C:(h + 1) * C],
-                  out=out[:, h * C:(h + 1) * C], max_row=pair.max_row, items=li)
+            for c0 in range(h * C, (h + 1) * C, _SPMM_MAX_F):  # a head wider than one SpMM call: column slices of it
+                c1 = min(c0 + _SPMM_MAX_F, (h + 1) * C)
+                _spmm(pair.rowptr, pair.col, w[h], None, xp[:, c0:c1], N, bias=None if bias_v is None else bias_v[c0:c1],
+                      out=out[:, c0:c1], max_row=pair.max_row, items=li)
         ctx.save_for_backward(xp, a_src, a_dst, w, att_s, att_d)
         ctx.pair, ctx.heads, ctx.slope = pair, heads, float(slope)
         ctx.att_shape = att_src.shape
@@ -864,7 +869,9 @@ class _GATAggregate(torch.autograd.Function):
         ws_seg = _lib.workspace(L.ceeg_segment_sum_items_ws_bytes(n_lt), xp.device) if n_lt else None
         for h in range(heads):
             gs, xs = g[:, h * C:(h + 1) * C], xp[:, h * C:(h + 1) * C]
-            _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, gs, N, out=dxp[:, h * C:(h + 1) * C], max_row=pair.max_trow, items=lt)
+            for c0 in range(h * C, (h + 1) * C, _SPMM_MAX_F):
+                c1 = min(c0 + _SPMM_MAX_F, (h + 1) * C)
+                _spmm(pair.t_rowptr, pair.t_col, w[h], pair.t_perm, g[:, c0:c1], N, out=dxp[:, c0:c1], max_row=pair.max_trow, items=lt)
             _lib.check(L.ceeg_gat_attn_bwd(pair.rowptr.data_ptr(), pair.col.data_ptr(), w[h].data_ptr(), a_src[h].data_ptr(),
                                            a_dst[h].data_ptr(), gs.data_ptr(), gs.stride(0), xs.data_ptr(), xs.stride(0), N, pair.nnz, C,
                                            slope, dl.data_ptr(), d_adst[h].data_ptr(), _lib.stream()), "ceeg_gat_attn_bwd")
@@ -876,7 +883,7 @@ class _GATAggregate(torch.autograd.Function):
         _lib.check(L.ceeg_gat_scores_bwd(xp.data_ptr(), xp.stride(0), att_s.data_ptr(), att_d.data_ptr(), d_asrc.data_ptr(), d_adst.data_ptr(),
                                          N, heads, C, dxp.data_ptr(), dxp.stride(0), d_att[0].data_ptr(), d_att[1].data_ptr(), ws.data_ptr(),
                                          ws.numel(), _lib.stream()), "ceeg_gat_scores_bwd")
-        d_bias = _colsum(g) if ctx.has_bias else None
+        d_bias = torch.cat([_colsum(g[:, c0:c0 + _SPMM_MAX_F]) for c0 in range(0, HC, _SPMM_MAX_F)]) if ctx.has_bias else None
         return dxp, d_att[0].view(ctx.att_shape), d_att[1].view(ctx.att_shape), d_bias, None, None, None
 
 
@@ -884,12 +891,13 @@ class GATConv(nn.Module):
     """PyG-style GATConv(in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_self_loops=True,
     bias=True) for one node set: x' = x W^T;  alpha_ij = softmax_j(leaky_relu(<x'_j, att_src> + <x'_i, att_dst>));
     out_i = sum_j alpha_ij x'_j (+ bias).  State-dict keys `lin_src.weight` (shared source/target transform),
-    `att_src`, `att_dst` [1, heads, out], `bias`.  out_channels must be a multiple of 4 and <= 256 per head."""
+    `att_src`, `att_dst` [1, heads, out], `bias`.  out_channels must be a multiple of 4 and <= 2048 per head (the reference's
+    conditioner layers are GATConv(768, 2048) and GATConv(2048, 2048), scripts/models.py:105-110, scripts/run.py:295)."""
 
     def __init__(self, in_channels, out_channels, heads=1, concat=True, negative_slope=0.2, add_self_loops=True, bias=True):
         super().__init__()
-        if out_channels % 4 or out_channels > 256:
-            raise ValueError("out_channels must be a multiple of 4 and <= 256")
+        if out_channels % 4 or out_channels > 2048 or heads * out_channels > 16384:
+            raise ValueError("out_channels must be a multiple of 4 and <= 2048 (heads * out_channels <= 16384)")
         if not add_self_loops:
             raise NotImplementedError("the CSR built for attention always carries one self-loop per node")
         self.in_channels, self.out_channels, self.heads, self.concat = in_channels, out_channels, int(heads), bool(concat)

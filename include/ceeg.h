@@ -281,7 +281,8 @@ int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, vo
  *   backward: dw[p] = <g[row p], xp[col p]>;  de[p] = w[p] (dw[p] - sum_k w[k] dw[k]);
  *             dl[p] = de[p] * (a_src[col p] + a_dst[row p] > 0 ? 1 : slope);  d_adst[i] = sum_{p in row i} dl[p];
  *             d_asrc[j] = sum of dl over the entries whose source is j = ceeg_segment_sum_perm over the transposed CSR.
- * g, xp: [N, ld] fp32 with C columns (C % 4 == 0, C <= 256; a head's column slice of a wider matrix is fine). */
+ * g, xp: [N, ld] fp32 with C columns (C % 4 == 0, C <= 2048 - the reference's layers are 2048 wide -; a head's column slice
+ * of a wider matrix is fine). */
 int ceeg_gat_softmax_fwd(const int32_t* rowptr, const int32_t* col, const float* a_src, const float* a_dst,
                          int64_t N, int64_t nnz, float slope, float* w, void* stream);
 int ceeg_gat_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* w, const float* a_src,
@@ -292,7 +293,7 @@ int ceeg_gat_attn_bwd(const int32_t* rowptr, const int32_t* col, const float* w,
  * Their backward, fused with the accumulation into the gradient of xp (dxp holds the aggregation's share on entry):
  *   dxp[n, h, :] += d_asrc[h*N+n] att_src[h, :] + d_adst[h*N+n] att_dst[h, :]
  *   d_att_src[h*C + c] = sum_n d_asrc[h*N+n] xp[n, h*C + c]   (d_att_dst likewise; block partials in a fixed order, fp64
- *   across blocks: deterministic).  C % 4 == 0, C <= 256, H*C <= 1024. */
+ *   across blocks: deterministic).  C % 4 == 0, C <= 2048, H*C <= 16384. */
 int ceeg_gat_scores_fwd(const float* xp, int64_t ldx, const float* att_src, const float* att_dst, int64_t N, int H, int C,
                         float* a_src, float* a_dst, void* stream);
 size_t ceeg_gat_scores_bwd_ws_bytes(int64_t N, int H, int C);

@@ -242,7 +242,7 @@ def test_gat_entry_points_reject_bad_arguments():
             d[0].data_ptr(), d[1].data_ptr())
     assert L.ceeg_gat_scores_bwd(*args, ws.data_ptr(), 16, st) < 0                       # workspace too small
     assert L.ceeg_gat_scores_bwd(*args, None, ws.numel(), st) < 0
-    assert L.ceeg_gat_scores_bwd(*args[:8], 260, *args[9:], ws.data_ptr(), ws.numel(), st) < 0  # C > 256
+    assert L.ceeg_gat_scores_bwd(*args[:8], 2052, *args[9:], ws.data_ptr(), ws.numel(), st) < 0  # C > 2048
     rp = torch.zeros(N + 1, dtype=torch.int32, device="cuda")
     out = torch.empty(N, device="cuda")
     v = torch.zeros(1, device="cuda")

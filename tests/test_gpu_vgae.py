@@ -299,7 +299,8 @@ def test_config1_plumbing_csv_to_training(tmp_path):
 
 @pytest.mark.parametrize("N,E,Fi,C,H,concat", [(3000, 40000, 48, 64, 1, True), (1500, 20000, 32, 16, 4, True), (800, 12000, 20, 8, 2, False),
                                                (2000, 300000, 16, 128, 1, True), (50, 60, 8, 4, 1, True), (1200, 90000, 24, 256, 1, True),
-                                               (900, 9000, 12, 192, 2, True)])
+                                               (900, 9000, 12, 192, 2, True), (300, 4000, 40, 2048, 1, True), (400, 30000, 16, 640, 2, True),
+                                               (250, 2000, 24, 1100, 1, False)])
 def test_gatconv_fwd_bwd_vs_oracle(N, E, Fi, C, H, concat):
     """GATConv: output and every gradient (input, transform, both attention vectors, bias) against the
     written-out PyG formulas; rows longer than 64 entries (multi-batch softmax) in the dense case; pre-existing
