@@ -8,3 +8,4 @@ from .models import (  # noqa: F401
     MAX_LOGSTD, CsrPair, EventGraph, GCNConv, InnerProductDecoder, VariationalGCNEncoder, VGAE, VGAEVQ,
     ConditionalVGAEVQ, GATConv, negative_sampling, sigma_params,
 )
+from .conditioner import GraphConditioner  # noqa: F401

@@ -298,3 +298,38 @@ def ref_graph_layer_norm(x, batch, num_graphs, weight=None, bias=None, eps=1e-5)
     var = torch.zeros(num_graphs, dtype=x.dtype).index_add_(0, batch, (xc * xc).sum(1)) / cnt
     out = xc / (var + eps).sqrt()[batch][:, None]
     return out if weight is None else out * weight + bias
+
+
+class RefGraphConditioner(nn.Module):
+    """Restatement of the reference's GraphConditioner (scripts/models.py:95-122) on the written-out PyG formulas above:
+    token attention pooling bmm(hidden^T, attn(hidden)) (:118-119), then per layer GATConv -> LayerNorm(mode='graph') ->
+    ReLU (:105-110), then GlobalAttention (:112-113,122).  Parameter names follow the reference's state dict
+    (torch_geometric.nn.Sequential numbers every module, the parameter-free ReLUs included).  Parity unpinned
+    (torch_geometric is not installed; the token encoder is a plug-in and out of scope)."""
+
+    def __init__(self, embedding, embedding_hidden_size, graph_layer_sizes):
+        super().__init__()
+        self.embedding = embedding
+        self.attn = nn.Linear(embedding_hidden_size, 1)
+        seq = nn.Module()
+        self.n_layers = len(graph_layer_sizes)
+        sizes = [embedding_hidden_size] + list(graph_layer_sizes)
+        for i, (a, b) in enumerate(zip(sizes[:-1], sizes[1:])):
+            seq.add_module(f"module_{3 * i}", RefGATConv(a, b))
+            ln = nn.Module()
+            ln.weight, ln.bias = nn.Parameter(torch.ones(b)), nn.Parameter(torch.zeros(b))
+            seq.add_module(f"module_{3 * i + 1}", ln)
+        self.graph_sequential_model = seq
+        pool = nn.Module()
+        pool.gate_nn = nn.Linear(graph_layer_sizes[-1], 1)
+        self.pooling_layer = pool
+
+    def forward(self, input):
+        hidden = self.embedding(input_ids=input.input_ids, attention_mask=input.attention_mask).last_hidden_state
+        x = torch.bmm(hidden.permute(0, 2, 1), self.attn(hidden)).squeeze(2)
+        batch, G = input.input_ids_batch, input.num_graphs
+        for i in range(self.n_layers):
+            conv = getattr(self.graph_sequential_model, f"module_{3 * i}")
+            ln = getattr(self.graph_sequential_model, f"module_{3 * i + 1}")
+            x = torch.relu(ref_graph_layer_norm(conv(x, input.edge_index), batch, G, ln.weight, ln.bias))
+        return ref_global_attention(x, self.pooling_layer.gate_nn(x).view(-1), batch, G)

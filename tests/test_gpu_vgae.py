@@ -610,3 +610,55 @@ def test_decoder_code_form_with_condition_columns():
     (r2 * 1.3).backward()
     _close(r1, r2, rtol=1e-5)
     _close(gz1, zc.grad[:, :D], rtol=1e-4, atol_rel=1e-5)
+
+
+def test_graph_conditioner_vs_oracle():
+    """The reference's GraphConditioner (scripts/models.py:95-122; SURVEY.md section 8(f) N1 + N4) end to end on a collated
+    batch: token attention pooling -> 3 x [GATConv -> graph LayerNorm -> ReLU] -> GlobalAttention, with a stand-in token
+    encoder (fixed hidden states).  The reference's state-dict layout loads; output and every gradient against the
+    restatement."""
+    from types import SimpleNamespace
+    from causal_eeg_vae_amd.conditioner import GraphConditioner
+    from causal_eeg_vae_amd.synth import collate_graphs
+    from oracle import ref_torch
+    torch.manual_seed(5)
+    sizes = [40, 1, 130, 77]
+    eis = [torch.from_numpy(_graph(n, max(1, 6 * n), 900 + n)) if n > 1 else torch.zeros(2, 0, dtype=torch.int64) for n in sizes]
+    ei, batch, N = collate_graphs(eis, sizes)
+    T, H = 7, 48
+    hidden = torch.randn(N, T, H)
+
+    class Enc(torch.nn.Module):  # stand-in for the token encoder: returns the hidden states it was given
+        def __init__(self, h):
+            super().__init__()
+            self.h = torch.nn.Parameter(h.clone())
+
+        def forward(self, input_ids=None, attention_mask=None):
+            return SimpleNamespace(last_hidden_state=self.h)
+
+    ref = ref_torch.RefGraphConditioner(Enc(hidden), H, [64, 320, 32])
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1 and p is not ref.embedding.h:
+                p.normal_(0.5, 0.3)
+    mine = GraphConditioner(Enc(hidden), H, [64, 320, 32])
+    missing = mine.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    mine = mine.cuda()
+    inp = SimpleNamespace(input_ids=None, attention_mask=None, edge_index=ei, input_ids_batch=batch, num_graphs=len(sizes))
+    inp_gpu = SimpleNamespace(input_ids=None, attention_mask=None, edge_index=ei.cuda(), input_ids_batch=batch.cuda(), num_graphs=len(sizes))
+    r = torch.randn(len(sizes), 32)
+    out_ref = ref(inp)
+    (out_ref * r).sum().backward()
+    out = mine(inp_gpu)
+    (out * r.cuda()).sum().backward()
+    assert out.shape == (len(sizes), 32)
+    _close(out, out_ref, rtol=1e-3, atol_rel=1e-4)
+    want = dict(ref.named_parameters())
+    scale = max(float(w.grad.abs().max()) for w in want.values())
+    for name, p in mine.named_parameters():
+        # a gradient that is analytically ~0 (the attention vectors in front of a graph LayerNorm: 1e-9 here) is rounding
+        # noise in both implementations: the absolute floor is tied to the largest gradient of the model
+        g, w = p.grad.cpu().double(), want[name].grad.double()
+        tol = 5e-3 * w.abs() + 1e-3 * float(w.abs().max()) + 1e-6 * scale
+        assert bool(((g - w).abs() <= tol).all()), (name, float((g - w).abs().max()), float(w.abs().max()))
