@@ -35,7 +35,8 @@ class Trainer:
         self.model = model
         self.world_size = int(world_size)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.opt = torch.optim.Adam(self.params, lr=lr)  # scripts/run.py:56
+        # scripts/run.py:56; on the GPU the single-kernel (fused) form of the same update: 7 launches -> 1 per step
+        self.opt = torch.optim.Adam(self.params, lr=lr, fused=all(p.is_cuda for p in self.params))
         self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt)  # scripts/run.py:57 (defaults)
         self.step_idx = 0
         if self.world_size > 1:
