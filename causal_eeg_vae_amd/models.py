@@ -406,6 +406,9 @@ class _ReparamVQ(torch.autograd.Function):
         ctx.save_for_backward(ml, epsc, wc, idx, z)
         ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
         ctx.mark_non_differentiable(scal[1], idx)
+        # an output nobody differentiates (z in the training step) must not come back as an [N, D] tensor of zeros: that is a
+        # 0.5 GB fill plus a 0.5 GB read inside the fused backward; the backward takes None for it
+        ctx.set_materialize_grads(False)
         return z, kl, scal[0], z_q, scal[1], idx
 
     @staticmethod
