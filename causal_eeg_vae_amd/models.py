@@ -352,6 +352,7 @@ class _ReparamKL(torch.autograd.Function):
                                          ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_kl_fwd")
         ctx.save_for_backward(mu_v, ls_v, epsc)
         ctx.seed, ctx.training, ctx.log_var, ctx.fused = int(seed), int(training), int(log_var), fused
+        ctx.set_materialize_grads(False)  # an unused output's gradient arrives as None (the kernel takes NULL), not as zeros
         return z, kl
 
     @staticmethod

@@ -44,6 +44,7 @@ class _VQFunction(torch.autograd.Function):
         ctx.beta, ctx.dtype = float(beta), dtype
         loss, ppl = scal[0], scal[1]
         ctx.mark_non_differentiable(ppl, idx)
+        ctx.set_materialize_grads(False)  # an undifferentiated z_q (or loss) comes back as None, not as a [B, D] tensor of zeros
         return loss, z_q, ppl, idx
 
     @staticmethod
