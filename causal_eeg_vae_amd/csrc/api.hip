@@ -12,6 +12,7 @@ extern "C" const char* ceeg_strerror(int code) {
     case CEEG_EWORKSPACE: return "workspace missing, misaligned or smaller than the *_ws_bytes() query";
     case CEEG_ELAUNCH: return "HIP kernel launch failed";
     case CEEG_ENODEVICE: return "no gfx950 (MI355X) device is current";
+    case CEEG_ETOOBIG: return "problem needs more scratch than the fixed in-library buffer of this entry point holds";
     default: return "unknown ceeg error";
   }
 }

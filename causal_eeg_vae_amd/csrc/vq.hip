@@ -18,6 +18,7 @@
 // The codebook is streamed through LDS in chunks of CT codes; z tiles live in registers for the whole
 // kernel (each z element is read from HBM exactly once).
 #include <stdlib.h>
+#include <mutex>
 #include "ceeg_internal.h"
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -1199,17 +1200,21 @@ extern "C" size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype)
   return vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr);
 }
 
-extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
-                               void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
-                               void* ws, size_t ws_bytes, void* stream) {
+namespace {
+// argument checks shared by the two forward entry points (before any launch)
+int vq_forward_check(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, const void* z_q, const int64_t* idx,
+                     const float* loss, const float* perplexity) {
   if (!z || !W || !z_q || !idx || !loss || !perplexity || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
   if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
   if (D > 256 || n_e > 16384 || B > ((int64_t)1 << 31) * 128) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(z, 16) || !ceeg_aligned(z_q, 16) || !ceeg_aligned(W, 16)) return CEEG_EINVAL;
-  VqFwdWs w;
-  if (ws_bytes < vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
-  if (!ws || !ceeg_aligned(ws, 256) || vq_fwd_layout(B, n_e, D, dtype, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  return CEEG_OK;
+}
+
+// the forward's launches over an already carved workspace `w` (every word of it that a kernel reads is written by an
+// earlier kernel of the same call: nothing has to be zero on entry)
+int vq_forward_run(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta, void* z_q, int64_t* idx,
+                   float* loss, float* perplexity, uint32_t* hist, const VqFwdWs& w, hipStream_t st) {
   const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
   const int n_ep = (n_e + CT - 1) / CT * CT;
   int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
@@ -1253,6 +1258,61 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
                      loss, perplexity, hist);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
+}
+}  // namespace
+
+extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
+                               void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
+                               void* ws, size_t ws_bytes, void* stream) {
+  const int rc = vq_forward_check(z, W, B, n_e, D, dtype, z_q, idx, loss, perplexity);
+  if (rc != CEEG_OK) return rc;
+  VqFwdWs w;
+  if (ws_bytes < vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
+  if (!ws || !ceeg_aligned(ws, 256) || vq_fwd_layout(B, n_e, D, dtype, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  return vq_forward_run(z, W, B, n_e, D, dtype, beta, z_q, idx, loss, perplexity, hist, w, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------------------------------------- forward without a workspace
+// For callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc): the forward's
+// scratch (codebook image, code norms, per-block error partials, per-slice histograms) lives in a file-scope device array.
+// Every GPU the library runs on holds its own copy at its own address; host code never uses the array's NAME as a pointer
+// (it is a host-side stand-in) - the device address comes from hipGetSymbolAddress, once per device, and only that pointer
+// goes to kernels.
+namespace {
+constexpr size_t VQ_STATIC_SCRATCH_BYTES = (size_t)4 << 20;  // covers config 3 (4 Mi x 512 x 256: 2.63 MiB) in both dtypes
+static __device__ __align__(256) unsigned char vq_static_scratch[VQ_STATIC_SCRATCH_BYTES];
+constexpr int VQ_MAX_DEVICES = 64;
+void* g_scratch_ptr[VQ_MAX_DEVICES];  // per device; written once under g_scratch_mu
+std::mutex g_scratch_mu;
+
+// device address of THIS device's copy of the array (looked up on the first call on the device, with that device current)
+int vq_static_scratch_ptr(void** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= VQ_MAX_DEVICES) return CEEG_ENODEVICE;
+  std::lock_guard<std::mutex> lock(g_scratch_mu);
+  if (g_scratch_ptr[dev] == nullptr) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(vq_static_scratch)) != hipSuccess || p == nullptr) return CEEG_ENODEVICE;
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return CEEG_OK;
+}
+}  // namespace
+
+extern "C" size_t ceeg_vq_forward_static_max_bytes(void) { return VQ_STATIC_SCRATCH_BYTES; }
+
+extern "C" int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
+                                      void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist, void* stream) {
+  const int rc = vq_forward_check(z, W, B, n_e, D, dtype, z_q, idx, loss, perplexity);
+  if (rc != CEEG_OK) return rc;
+  if (vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr) > VQ_STATIC_SCRATCH_BYTES) return CEEG_ETOOBIG;
+  void* scratch = nullptr;
+  const int rp = vq_static_scratch_ptr(&scratch);
+  if (rp != CEEG_OK) return rp;
+  VqFwdWs w;
+  if (vq_fwd_layout(B, n_e, D, dtype, scratch, VQ_STATIC_SCRATCH_BYTES, &w) == 0) return CEEG_ETOOBIG;
+  return vq_forward_run(z, W, B, n_e, D, dtype, beta, z_q, idx, loss, perplexity, hist, w, static_cast<hipStream_t>(stream));
 }
 
 // ---------------------------------------------------------------------------------------------- backward API

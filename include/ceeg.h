@@ -33,7 +33,8 @@ enum {
   CEEG_EUNSUPPORTED = -2, /* shape or dtype outside what the kernels implement */
   CEEG_EWORKSPACE = -3,   /* ws_bytes smaller than the ws_bytes() query */
   CEEG_ELAUNCH = -4,      /* hipGetLastError() != hipSuccess after a launch */
-  CEEG_ENODEVICE = -5     /* no HIP device / wrong architecture */
+  CEEG_ENODEVICE = -5,    /* no HIP device / wrong architecture */
+  CEEG_ETOOBIG = -6       /* sizes beyond the fixed scratch of an entry point that takes no workspace */
 };
 
 /* element types of z / z_q / features */
@@ -72,6 +73,20 @@ size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype);
 int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
                     void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist,
                     void* ws, size_t ws_bytes, void* stream);
+
+/* ceeg_vq_forward WITHOUT a workspace argument and without any allocation.  No counterpart in the reference: it exists
+ * for callers that cannot allocate device memory around the call - code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  Same kernels, same results bit for bit as ceeg_vq_forward; the scratch the kernels
+ * need (codebook image, code norms, per-block error partials, per-slice histograms) is a fixed array inside the library,
+ * ceeg_vq_forward_static_max_bytes() = 4 MiB per GPU the library runs on, held until the process ends.  A problem whose
+ * ceeg_vq_forward_ws_bytes() exceeds that (e.g. B = 4 Mi with n_e = 1024, D = 256) returns CEEG_ETOOBIG before any
+ * launch; config 3 (4 Mi x 512 x 256, both dtypes: 2.63 MiB) fits.  Calls no hipMalloc/hipFree or allocating routine.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE - serialise
+ * them.  Nothing in the array has to be zero between calls (every word a kernel reads is written earlier in the same
+ * call).  The one exception to "no global mutable state" above: the per-device address of the array, looked up once. */
+size_t ceeg_vq_forward_static_max_bytes(void);
+int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
+                           void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist, void* stream);
 
 /* Backward of A2 (closed form; autograd of quantizer.py:54-61):
  *   dz[b]  = g[b] + s*(2/(B*D))*(z[b]-W[idx[b]])              g = dL/dz_q (NULL = 0), s = dL/dloss
