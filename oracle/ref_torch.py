@@ -30,12 +30,18 @@ class RefVectorQuantizer(nn.Module):
         with torch.no_grad():
             self.embedding.weight.uniform_(-1.0 / n_e, 1.0 / n_e)       # quantizer.py:23
 
-    def forward(self, z):
+    def forward(self, z, force_idx=None):
+        """force_idx ([B] or [B,1] int64): take these codes instead of the argmin - the checker's way to compare losses and
+        gradients on rows whose top-2 gap is below the rounding of the distances (the caller asserts that gap first);
+        `self.last_d` keeps the distance matrix for that assertion."""
         W = self.embedding.weight
         zz = (z * z).sum(dim=1, keepdim=True)                           # quantizer.py:43
         ee = (W * W).sum(dim=1)                                         # quantizer.py:44
         d = zz + ee - 2.0 * (z @ W.t())                                 # quantizer.py:43-45
+        self.last_d = d.detach()
         idx = d.argmin(dim=1, keepdim=True)                             # quantizer.py:48
+        if force_idx is not None:
+            idx = force_idx.view(-1, 1).to(torch.int64)
         onehot = torch.zeros(z.shape[0], self.n_e, dtype=z.dtype, device=z.device)
         onehot.scatter_(1, idx, 1.0)                                    # quantizer.py:49-51
         zq = onehot @ W                                                 # quantizer.py:54
@@ -179,9 +185,34 @@ def kl_loss(mu, logstd):
     return -0.5 * torch.mean(torch.sum(1 + 2 * logstd - mu ** 2 - logstd.exp() ** 2, dim=1))
 
 
+class _SigmoidOnF32Grid(torch.autograd.Function):
+    """float64 form of the reference's fp32 `torch.sigmoid` inside the literal `+EPS` loss.  torch evaluates the fp32
+    sigmoid as 1 / (1 + exp(-v)) (CPU and GPU kernels alike); the three fp32 roundings of that formula are reproduced
+    here - exp(-v) exact then rounded, the sum rounded, the quotient rounded - and the derivative p(1-p) is taken from the
+    ROUNDED p (torch's sigmoid backward uses the saved output).  These roundings are part of the semantics, not noise:
+    for v > ~17 the sum 1 + exp(-v) IS 1.0f, which is what caps a term at -log(1e-15) = 34.54 and zeroes its gradient
+    (SURVEY.md section 8 A6), and between v ~ 9 and 17 the complement 1-p is a small multiple of 2^-24, so a term
+    -log(1-p+EPS) moves by percents with the rounding of p.  Everything else (dot products, logs, means, the backward
+    sums) stays exact float64."""
+
+    @staticmethod
+    def forward(ctx, v):
+        e = torch.exp(-v).float()                 # correctly rounded expf
+        p = (1.0 / (1.0 + e)).double()            # fp32 add, fp32 divide (both correctly rounded by IEEE)
+        ctx.save_for_backward(p)
+        return p
+
+    @staticmethod
+    def backward(ctx, g):
+        (p,) = ctx.saved_tensors
+        return g * p * (1 - p)
+
+
 def decode(z, edge_index, sigmoid=True):
     v = (z[edge_index[0]] * z[edge_index[1]]).sum(dim=1)
-    return torch.sigmoid(v) if sigmoid else v
+    if not sigmoid:
+        return v
+    return _SigmoidOnF32Grid.apply(v) if v.dtype == torch.float64 else torch.sigmoid(v)
 
 
 def recon_loss(z, pos_edge_index, neg_edge_index):
@@ -228,9 +259,11 @@ class RefVGAEVQ(nn.Module):
         self.encoder = RefEncoder(f_in, latent)
         self.vector_quantization = RefVectorQuantizer(n_e, latent, beta)
 
-    def forward(self, x, edge_index, eps, neg_edge_index, neg_valid=None, batch=None, condition=None):
+    def forward(self, x, edge_index, eps, neg_edge_index, neg_valid=None, batch=None, condition=None, force_idx=None):
         """batch / condition: config 4's conditional form - the per-graph condition c[batch] is concatenated to the
-        encoder input (scripts/models.py:162) and to the latent before decoding (scripts/models.py:259)."""
+        encoder input (scripts/models.py:162) and to the latent before decoding (scripts/models.py:259).
+        force_idx: see RefVectorQuantizer.forward.  Runs in the dtype of its parameters and inputs (call .double() on the
+        module and the inputs for the fp64-accumulated form the GPU tests compare against)."""
         cn = None if condition is None else condition[batch]
         if cn is not None:
             x = torch.cat((x, cn), dim=1)
@@ -238,7 +271,7 @@ class RefVGAEVQ(nn.Module):
         logstd = logstd.clamp(max=MAX_LOGSTD)
         z = reparametrize(mu, logstd, eps)
         kl = kl_loss(mu, logstd)
-        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z)
+        vq_loss, z_q, ppl, _, idx = self.vector_quantization(z, force_idx)
         if cn is not None:
             z_q = torch.cat((z_q, cn), dim=1)
         pos = -torch.log(decode(z_q, edge_index) + EPS).mean()

@@ -82,7 +82,9 @@ def test_spmm_vs_oracle_and_determinism(F):
     y = torch.randn(N, F, device="cuda")
     lhs = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, 2 * x + y, N)
     rhs = 2 * _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, x, N) + _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, y, N)
-    torch.testing.assert_close(lhs, rhs, rtol=1e-4, atol=1e-4)
+    # both sides fp32, each within rounding of the exact sum: they differ by at most a few ulp of sum |terms|
+    mag = _spmm(g.gcn.rowptr, g.gcn.col, g.gcn_val, None, (2 * x + y).abs(), N) + 1e-30
+    assert float(((lhs - rhs).abs() / mag).max()) < 1e-5
 
 
 @pytest.mark.parametrize("N,E", [(1, 0), (2, 1), (7, 12), (33, 100), (96, 145), (130, 900)])
@@ -130,7 +132,8 @@ def test_philox_eps_matches_oracle():
     mu = torch.zeros(N, D, device="cuda"); ls = torch.zeros(N, D, device="cuda")
     z, kl = _ReparamKL.apply(mu, ls, None, 4242, True, False)  # z = eps exactly
     eps = c_oracle.philox_normal(4242, N * D).reshape(N, D)
-    np.testing.assert_allclose(z.cpu().numpy(), eps, rtol=2e-4, atol=2e-5)
+    # the Philox integers are bit-exact; the floats go through logf / sincosf of two different libms (device, glibc)
+    np.testing.assert_allclose(z.cpu().numpy(), eps, rtol=1e-5, atol=1e-6 * float(np.abs(eps).max()))
     assert abs(kl.item()) < 1e-6
 
 

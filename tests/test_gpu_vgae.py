@@ -1,15 +1,14 @@
-"""GPU parity: reparam+KL, decoder (edge-list and fused), GCNConv, and the full VGAE+VQ step vs the oracle."""
+"""GPU parity: reparam+KL, decoder (edge-list and fused), GCNConv, and the full VGAE+VQ step vs the oracle.
+
+Every float comparison is `_close` = rtol 1e-5, atol 1e-6 max|ref| (the north-star tolerance) against the oracle run in
+float64 on the same fp32 inputs (tests/_parity.py); no assertion in this file is conditional on another one's outcome."""
 import numpy as np
 import pytest
 import torch
 
+from _parity import close as _close, flipped_rows_are_near_ties, grads_close, to64
+
 pytestmark = pytest.mark.gpu
-
-
-def _close(a, b, rtol=1e-5, atol_rel=1e-6):
-    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
-    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
-    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol_rel * max(np.abs(b).max(), 1e-30))
 
 
 def _graph(N, E, seed):
@@ -30,11 +29,11 @@ def test_reparam_kl_fwd_bwd(N, D, fused, training):
     ml[::7, D:] = 11.5  # exercise the MAX_LOGSTD clamp (zero gradient there)
     eps = torch.randn(N, D)
     w = torch.randn(N, D)
-    a = ml.clone().requires_grad_(True)
+    a = ml.double().requires_grad_(True)
     mu, ls = a[:, :D], a[:, D:].clamp(max=ref_torch.MAX_LOGSTD)
-    z_ref = ref_torch.reparametrize(mu, ls, eps) if training else mu
+    z_ref = ref_torch.reparametrize(mu, ls, eps.double()) if training else mu
     kl_ref = ref_torch.kl_loss(mu, ls)
-    ((z_ref * w).sum() + 3.0 * kl_ref).backward()
+    ((z_ref * w.double()).sum() + 3.0 * kl_ref).backward()
     b = ml.clone().cuda().requires_grad_(True)
     if fused:
         z, kl = _ReparamKL.apply(b, None, eps.cuda(), 0, training, False)
@@ -43,14 +42,14 @@ def test_reparam_kl_fwd_bwd(N, D, fused, training):
     ((z * w.cuda()).sum() + 3.0 * kl).backward()
     _close(z, z_ref)
     _close(kl, kl_ref)
-    _close(b.grad, a.grad, rtol=2e-5)
+    _close(b.grad, a.grad)
 
 
 def test_reparam_log_var_variant():
     from causal_eeg_vae_amd.models import _ReparamKL
     mu = torch.randn(64, 16); lv = torch.randn(64, 16); eps = torch.randn(64, 16)
     z, _ = _ReparamKL.apply(mu.cuda(), lv.cuda(), eps.cuda(), 0, True, True)
-    _close(z, mu + eps * torch.exp(0.5 * lv))  # scripts/models.py:38-43
+    _close(z, mu.double() + eps.double() * torch.exp(0.5 * lv.double()))  # scripts/models.py:38-43
 
 
 @pytest.mark.parametrize("D", [128, 16, 256])
@@ -62,16 +61,17 @@ def test_edge_bce_and_recon_loss(D):
     neg = torch.from_numpy(np.random.default_rng(D).integers(0, N, (2, E)))
     z0 = torch.randn(N, D) * (2.0 / D ** 0.5)
     z0[:5] *= 12  # saturate some sigmoids: the literal +EPS form must match
-    a = z0.clone().requires_grad_(True)
-    ref_torch.recon_loss(a, ei, neg).backward()
+    a = z0.double().requires_grad_(True)
+    ref = ref_torch.recon_loss(a, ei, neg)
+    ref.backward()
     b = z0.clone().cuda().requires_grad_(True)
     model = VGAE(torch.nn.Identity())
     loss = model.recon_loss(b, ei.cuda(), neg.cuda())
     loss.backward()
-    _close(loss, ref_torch.recon_loss(z0, ei, neg))
-    _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+    _close(loss, ref)
+    _close(b.grad, a.grad)
     p = InnerProductDecoder()(b.detach(), ei.cuda())
-    _close(p, ref_torch.decode(z0, ei), rtol=1e-5, atol_rel=1e-6)
+    _close(p, ref_torch.decode(z0.double(), ei))
 
 
 @pytest.mark.parametrize("N,E,D", [(3000, 50000, 128), (500, 20000, 32), (2000, 3000, 256), (700, 30000, 64), (900, 9000, 4),
@@ -88,7 +88,7 @@ def test_fused_decoder_vs_oracle(N, E, D):
     s, sig, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_)
     assert 0 < (~valid).sum() < len(valid) or N > 1000 or N < 100  # the dense case must exercise the collision mask
     z0 = torch.randn(N, D) * (2.0 / D ** 0.5)
-    a = z0.clone().requires_grad_(True)
+    a = z0.double().requires_grad_(True)
     rows = np.repeat(np.arange(N), np.diff(rowptr))
     pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
     neg_ei = torch.from_numpy(np.stack([s, sig]).astype(np.int64))[:, torch.from_numpy(valid)]
@@ -99,7 +99,7 @@ def test_fused_decoder_vs_oracle(N, E, D):
     (rec * 1.7).backward()
     assert int(sums[2].item()) == int(valid.sum())  # valid-negative count is exact
     _close(rec, ref)
-    _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+    _close(b.grad, a.grad)
     rec2, _ = _FusedDecoder.apply(b, g, a_, b_, ainv)
     assert torch.equal(rec, rec2)
     # the four-pass backward (no row-side sums kept by the forward) gives the same gradient
@@ -107,7 +107,7 @@ def test_fused_decoder_vs_oracle(N, E, D):
     rec3, _ = _FusedDecoder.apply(c, g, a_, b_, ainv, False)
     (rec3 * 1.7).backward()
     assert torch.equal(rec3, rec)
-    _close(c.grad, b.grad, rtol=1e-4, atol_rel=1e-5)
+    _close(c.grad, a.grad)
 
 
 def test_gcnconv_fwd_bwd_and_state_dict():
@@ -122,20 +122,40 @@ def test_gcnconv_fwd_bwd_and_state_dict():
         ref.bias.normal_()
     conv = GCNConv(Fi, Fo).cuda()
     conv.load_state_dict(ref.state_dict())  # same keys: lin.weight, bias
+    ref = to64(ref)
     x = torch.randn(N, Fi)
     for w in (None, ew):
-        a = x.clone().requires_grad_(True)
-        out_ref = ref(a, ei, w)
+        a = x.double().requires_grad_(True)
+        out_ref = ref(a, ei, None if w is None else w.double())
         out_ref.square().sum().backward()
         b = x.clone().cuda().requires_grad_(True)
         g = EventGraph(ei.cuda(), N, None if w is None else w.cuda())
         out = conv(b, g)
         out.square().sum().backward()
         _close(out, out_ref)
-        _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
-        _close(conv.lin.weight.grad, ref.lin.weight.grad, rtol=1e-4, atol_rel=1e-5)
-        _close(conv.bias.grad, ref.bias.grad, rtol=1e-4, atol_rel=1e-5)
+        _close(b.grad, a.grad)
+        grads_close(conv, ref)
         conv.zero_grad(); ref.zero_grad()
+
+
+def _check_step_against_fp64_oracle(ref, model, loss, aux, args, kwargs):
+    """The fp64 oracle runs twice: unforced, to check that every code the GPU chose is the exact argmin or a near tie
+    (flipped_rows_are_near_ties), then with the GPU's codes forced, so that losses and EVERY parameter gradient are compared
+    unconditionally on identical discrete choices."""
+    ref = to64(ref)
+    x, ei, eps, neg_ei, valid = args
+    kw = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in kwargs.items()}
+    with torch.no_grad():
+        _, aux0 = ref(x.double(), ei, eps.double(), neg_ei, valid, **kw)
+    _close(aux["z"], aux0["z"])
+    n_flip = flipped_rows_are_near_ties(aux["idx"], ref.vector_quantization)
+    assert n_flip <= max(1, x.shape[0] // 1000)
+    loss_ref, aux_ref = ref(x.double(), ei, eps.double(), neg_ei, valid, force_idx=aux["idx"].cpu(), **kw)
+    loss_ref.backward()
+    for k in ("kl", "rec", "vq", "ppl"):
+        _close(aux[k], aux_ref[k], what=k)
+    _close(loss, loss_ref)
+    grads_close(model, ref)
 
 
 def test_full_step_vs_oracle():
@@ -157,21 +177,10 @@ def test_full_step_vs_oracle():
     s, sg, valid = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1])
     neg_ei = torch.from_numpy(np.stack([s, sg]).astype(np.int64))
     ei = torch.from_numpy(ei_np)
-    loss_ref, aux_ref = ref(x, ei, eps, neg_ei, torch.from_numpy(valid))
-    loss_ref.backward()
     g = EventGraph(ei.cuda(), N)
     loss, aux = model(x.cuda(), g, step=5, eps=eps.cuda(), sigma=sig)
     loss.backward()
-    _close(aux["z"], aux_ref["z"], rtol=1e-4, atol_rel=1e-5)
-    same = (aux["idx"].cpu() == aux_ref["idx"])
-    assert same.double().mean() > 0.999  # z differs by fp32 rounding between the two encoders: near-ties may flip
-    for k in ("kl", "rec", "vq"):
-        _close(aux[k], aux_ref[k], rtol=1e-4)
-    _close(loss, loss_ref, rtol=1e-4)
-    if bool(same.all()):
-        ref_params = dict(ref.named_parameters())
-        for name, p in model.named_parameters():
-            _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
+    _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), {})
 
 
 @pytest.mark.parametrize("per_graph,D,n_e", [(True, 12, 32), (False, 12, 32), (True, 64, 100), (False, 64, 100)])
@@ -200,22 +209,11 @@ def test_conditional_batched_step_vs_oracle(per_graph, D, n_e):
     if per_graph:
         assert np.array_equal(s // n, sg // n)  # every negative pair stays inside its graph
     neg_ei = torch.from_numpy(np.stack([s, sg]).astype(np.int64))
-    loss_ref, aux_ref = ref(x, ei, eps, neg_ei, torch.from_numpy(valid), batch=batch, condition=cond)
-    loss_ref.backward()
     g = EventGraph(ei.cuda(), N)
     loss, aux = model(x.cuda(), g, batch.cuda(), cond.cuda(), step=3, eps=eps.cuda(), sigma=sig, nodes_per_graph=n if per_graph else None)
     loss.backward()
     assert int(aux["dec_sums"][2].item()) == int(valid.sum())
-    _close(aux["z"], aux_ref["z"], rtol=1e-4, atol_rel=1e-5)
-    same = (aux["idx"].cpu() == aux_ref["idx"])
-    assert same.double().mean() > 0.999
-    for k in ("kl", "rec", "vq"):
-        _close(aux[k], aux_ref[k], rtol=1e-4)
-    _close(loss, loss_ref, rtol=1e-4)
-    if bool(same.all()):
-        ref_params = dict(ref.named_parameters())
-        for name, p in model.named_parameters():
-            _close(p.grad, ref_params[name].grad, rtol=1e-3, atol_rel=1e-4)
+    _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), dict(batch=batch, condition=cond))
 
 
 @pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (1000, 30000, 32, 16)])
@@ -255,7 +253,19 @@ def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e, monkeypatc
         os.environ.pop("CEEG_DEC_BWD_TWO_PASS", None)
         os.environ.pop("CEEG_DEC_BWD_GROUPED", None)
     assert torch.equal(grads[0], grads[1])
-    _close(x2.grad, grads[0], rtol=1e-4, atol_rel=1e-6)   # default (row per lane group) form: same sums, other order
+    # default (row per lane group) form: same sums, other order - both within tolerance of the exact (fp64) gradient
+    from oracle import ref_torch
+    ei_np = g.edge_index.cpu().numpy()
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s_, sg_, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    a64 = zq.cpu().double().requires_grad_(True)
+    ref = ref_torch.recon_loss(a64, torch.from_numpy(np.stack([col, rows]).astype(np.int64)),
+                               torch.from_numpy(np.stack([s_, sg_]).astype(np.int64))[:, torch.from_numpy(valid)])
+    (ref * 0.7).backward()
+    _close(r2, ref)
+    _close(x2.grad, a64.grad)
+    _close(grads[0], a64.grad)
 
 
 def test_config1_plumbing_csv_to_training(tmp_path):
@@ -315,18 +325,18 @@ def test_gatconv_fwd_bwd_vs_oracle(N, E, Fi, C, H, concat):
         ref.bias.normal_()
     conv = GATConv(Fi, C, heads=H, concat=concat).cuda()
     conv.load_state_dict(ref.state_dict())
+    ref = to64(ref)
     x = torch.randn(N, Fi)
     r = torch.randn(N, H * C if concat else C)
-    a = x.clone().requires_grad_(True)
+    a = x.double().requires_grad_(True)
     out_ref = ref(a, ei)
-    (out_ref * r).sum().backward()
+    (out_ref * r.double()).sum().backward()
     b = x.clone().cuda().requires_grad_(True)
     out = conv(b, ei.cuda())
     (out * r.cuda()).sum().backward()
-    _close(out, out_ref, rtol=1e-4, atol_rel=1e-5)
-    _close(b.grad, a.grad, rtol=1e-3, atol_rel=1e-4)
-    for name, p in conv.named_parameters():
-        _close(p.grad, dict(ref.named_parameters())[name].grad, rtol=1e-3, atol_rel=1e-4)
+    _close(out, out_ref)
+    _close(b.grad, a.grad)
+    grads_close(conv, ref)
     grads = {name: p.grad.clone() for name, p in conv.named_parameters()}
     bg = b.grad.clone()
     conv.zero_grad(set_to_none=True)
@@ -349,31 +359,32 @@ def test_global_attention_and_graph_layernorm_vs_oracle():
     for F in (2048, 12):
         torch.manual_seed(F)
         gate_nn = torch.nn.Linear(F, 1)
+        gate64 = to64(gate_nn)
         x = torch.randn(N, F)
         r = torch.randn(G, F)
-        a = x.clone().requires_grad_(True)
-        ref = ref_torch.ref_global_attention(a, gate_nn(a).view(-1), batch, G)
-        (ref * r).sum().backward()
-        gw = gate_nn.weight.grad.clone(); gate_nn.zero_grad()
+        a = x.double().requires_grad_(True)
+        ref = ref_torch.ref_global_attention(a, gate64(a).view(-1), batch, G)
+        (ref * r.double()).sum().backward()
+        gw = gate64.weight.grad.clone()
         pool = GlobalAttention(gate_nn).cuda()
         b = x.clone().cuda().requires_grad_(True)
         out = pool(b, batch.cuda(), G)
         (out * r.cuda()).sum().backward()
-        _close(out, ref, rtol=1e-4, atol_rel=1e-5)
-        _close(b.grad, a.grad, rtol=1e-3, atol_rel=1e-4)
-        _close(pool.gate_nn.weight.grad, gw, rtol=1e-3, atol_rel=1e-4)
+        _close(out, ref)
+        _close(b.grad, a.grad)
+        _close(pool.gate_nn.weight.grad, gw)
         gate_nn.cpu()
         ln = GraphLayerNorm(F).cuda()
         with torch.no_grad():
             ln.weight.normal_(); ln.bias.normal_()
-        a2 = x.clone().requires_grad_(True)
-        ref2 = ref_torch.ref_graph_layer_norm(a2, batch, G, ln.weight.detach().cpu(), ln.bias.detach().cpu())
-        (ref2 * x).sum().backward()
+        a2 = x.double().requires_grad_(True)
+        ref2 = ref_torch.ref_graph_layer_norm(a2, batch, G, ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double())
+        (ref2 * x.double()).sum().backward()
         b2 = x.clone().cuda().requires_grad_(True)
         out2 = ln(b2, batch.cuda(), G)
         (out2 * x.cuda()).sum().backward()
-        _close(out2, ref2, rtol=1e-4, atol_rel=1e-5)
-        _close(b2.grad, a2.grad, rtol=1e-3, atol_rel=1e-4)
+        _close(out2, ref2)
+        _close(b2.grad, a2.grad)
 
 
 @pytest.mark.parametrize("D", [128, 32])
@@ -396,7 +407,7 @@ def test_fused_decoder_indegree_hubs(D):
     rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
     s, sig, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_)
     z0 = torch.randn(N, D) * (1.5 / D ** 0.5)
-    a = z0.clone().requires_grad_(True)
+    a = z0.double().requires_grad_(True)
     rows = np.repeat(np.arange(N), np.diff(rowptr))
     pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
     neg_ei = torch.from_numpy(np.stack([s, sig]).astype(np.int64))[:, torch.from_numpy(valid)]
@@ -410,7 +421,7 @@ def test_fused_decoder_indegree_hubs(D):
         outs.append((rec.detach(), b.grad))
         assert int(sums[2].item()) == int(valid.sum())
         _close(rec, ref)
-        _close(b.grad, a.grad, rtol=1e-4, atol_rel=1e-5)
+        _close(b.grad, a.grad)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
@@ -471,9 +482,6 @@ def _codes_case(ei_np, N, D, n_e, sig, mod=None, seed=3):
     (r1, s1, g1), (r2, s2, g2), (r0, s0, g0) = outs
     assert torch.equal(r1, r2) and torch.equal(s1, s2) and torch.equal(g1, g2)     # bitwise reproducible
     assert float(s1[2]) == float(s0[2])                                            # valid-negative count is exact
-    _close(s1, s0, rtol=1e-5)
-    _close(r1, r0, rtol=1e-5)
-    _close(g1, g0, rtol=1e-4, atol_rel=1e-5)
     m = N if mod is None else mod
     rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
     rows = np.repeat(np.arange(N), np.diff(rowptr))
@@ -481,13 +489,14 @@ def _codes_case(ei_np, N, D, n_e, sig, mod=None, seed=3):
     has = set(zip(col.tolist(), rows.tolist()))
     valid = np.array([c != sr and (c, sr) not in has for c, sr in zip(col.tolist(), sig_rows.tolist())], dtype=bool)
     assert int(s1[2].item()) == int(valid.sum())
-    a = zq.clone().requires_grad_(True)
+    a = zq.double().requires_grad_(True)
     pos_ei = torch.from_numpy(np.stack([col, rows]).astype(np.int64))
     neg_ei = torch.from_numpy(np.stack([col, sig_rows]).astype(np.int64))[:, torch.from_numpy(valid)]
     ref = ref_torch.recon_loss(a, pos_ei, neg_ei)
     (ref * 0.7).backward()
-    _close(r1, ref, rtol=1e-5)
-    _close(g1, a.grad, rtol=1e-4, atol_rel=1e-5)
+    for r_, g_ in ((r1, g1), (r0, g0)):   # code form and table form of the row-gather kernels, each against the exact value
+        _close(r_, ref)
+        _close(g_, a.grad)
 
 
 @pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (2000, 30000, 64, 100), (1500, 20000, 256, 512), (900, 9000, 192, 7),
@@ -601,15 +610,27 @@ def test_decoder_code_form_with_condition_columns():
             os.environ.pop("CEEG_DEC_CODES", None)
     (r1, s1, gz1, gc1), (r0, s0, gz0, gc0) = outs
     assert float(s1[2]) == float(s0[2])
-    _close(r1, r0, rtol=1e-5)
-    _close(gz1, gz0, rtol=1e-4, atol_rel=1e-5)
-    _close(gc1, gc0, rtol=1e-4, atol_rel=1e-5)
-    # the plain concatenation (no table at all) agrees too
+    # the plain concatenation (no table at all)
     zc = torch.cat((W[idx.long()], cond.index_select(0, batch)), dim=1).clone().requires_grad_(True)
     r2, s2 = _FusedDecoder.apply(zc, g, a_, b_, ainv, True, n)
     (r2 * 1.3).backward()
-    _close(r1, r2, rtol=1e-5)
-    _close(gz1, zc.grad[:, :D], rtol=1e-4, atol_rel=1e-5)
+    # all three against the fp64 oracle on the concatenated matrix with the same explicit negatives
+    from oracle import ref_torch
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s_, sg_, valid = ref_torch.sigma_negatives_np(rowptr, col, N, a_, b_, n)
+    rows = np.repeat(np.arange(N), np.diff(rowptr))
+    z64 = W[idx.long()].cpu().double().requires_grad_(True)
+    c64 = cond.cpu().double().requires_grad_(True)
+    ref = ref_torch.recon_loss(torch.cat((z64, c64[batch.cpu()]), dim=1), torch.from_numpy(np.stack([col, rows]).astype(np.int64)),
+                               torch.from_numpy(np.stack([s_, sg_]).astype(np.int64))[:, torch.from_numpy(valid)])
+    (ref * 1.3).backward()
+    assert int(s1[2]) == int(valid.sum())
+    for r_, gz_, gc_ in ((r1, gz1, gc1), (r0, gz0, gc0)):
+        _close(r_, ref)
+        _close(gz_, z64.grad)
+        _close(gc_, c64.grad)
+    _close(r2, ref)
+    _close(zc.grad[:, :D], z64.grad)
 
 
 def test_graph_conditioner_vs_oracle():
@@ -645,20 +666,22 @@ def test_graph_conditioner_vs_oracle():
     missing = mine.load_state_dict(ref.state_dict(), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     mine = mine.cuda()
+    ref = to64(ref)
     inp = SimpleNamespace(input_ids=None, attention_mask=None, edge_index=ei, input_ids_batch=batch, num_graphs=len(sizes))
     inp_gpu = SimpleNamespace(input_ids=None, attention_mask=None, edge_index=ei.cuda(), input_ids_batch=batch.cuda(), num_graphs=len(sizes))
     r = torch.randn(len(sizes), 32)
     out_ref = ref(inp)
-    (out_ref * r).sum().backward()
+    (out_ref * r.double()).sum().backward()
     out = mine(inp_gpu)
     (out * r.cuda()).sum().backward()
     assert out.shape == (len(sizes), 32)
-    _close(out, out_ref, rtol=1e-3, atol_rel=1e-4)
+    _close(out, out_ref)
     want = dict(ref.named_parameters())
     scale = max(float(w.grad.abs().max()) for w in want.values())
     for name, p in mine.named_parameters():
-        # a gradient that is analytically ~0 (the attention vectors in front of a graph LayerNorm: 1e-9 here) is rounding
-        # noise in both implementations: the absolute floor is tied to the largest gradient of the model
+        # a gradient that is analytically ~0 (the attention vectors in front of a graph LayerNorm, which removes their
+        # common shift: 1e-9 of the model's largest gradient) is a difference of O(1) terms: its absolute floor is tied to
+        # the largest gradient of the model, the relative part stays the north-star 1e-5
         g, w = p.grad.cpu().double(), want[name].grad.double()
-        tol = 5e-3 * w.abs() + 1e-3 * float(w.abs().max()) + 1e-6 * scale
-        assert bool(((g - w).abs() <= tol).all()), (name, float((g - w).abs().max()), float(w.abs().max()))
+        tol = 1e-5 * w.abs() + 1e-6 * float(w.abs().max()) + 1e-6 * scale
+        assert bool(((g - w).abs() <= tol).all()), (name, float((g - w).abs().max()), float(w.abs().max()), scale)

@@ -39,17 +39,14 @@ def test_fp32_golden_and_oracle(path):
     assert torch.equal(onehot.argmax(1), idx[:, 0])
     np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-5, atol=1e-7)
     np.testing.assert_allclose(ppl.item(), o["perplexity"], rtol=1e-5)
-    ref_idx = g["idx"][:, 0]
-    if (gi == ref_idx).all():  # same indices as the literal reference: every float output must match it too
-        np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5, atol=1e-7)
-        np.testing.assert_allclose(ppl.item(), g["perplexity"], rtol=1e-5)
-        np.testing.assert_allclose(z_q.detach().cpu().numpy(), g["z_q"], rtol=1e-5, atol=1e-6)
-        np.testing.assert_allclose(z.grad.cpu().numpy(), g["dz"], rtol=1e-5, atol=1e-6 * np.abs(g["dz"]).max())
-        np.testing.assert_allclose(vq.embedding.weight.grad.cpu().numpy(), g["dW"], rtol=1e-5, atol=1e-6 * max(np.abs(g["dW"]).max(), 1e-30))
-    else:  # rounding-sensitive rows only (top-2 gap below a few ulp of the distance magnitude)
-        bad = np.nonzero(gi != ref_idx)[0]
-        assert len(bad) <= max(1, len(gi) // 50)
-        assert (g["gap64"][bad] < 1e-4).all()
+    # the literal reference (live scripts/quantizer.py, MKL summation order unknown): its indices are reproduced on every
+    # golden case, so every float output and both gradients are compared with it unconditionally
+    np.testing.assert_array_equal(gi, g["idx"][:, 0])
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ppl.item(), g["perplexity"], rtol=1e-5)
+    np.testing.assert_allclose(z_q.detach().cpu().numpy(), g["z_q"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g["dz"], rtol=1e-5, atol=1e-6 * np.abs(g["dz"]).max())
+    np.testing.assert_allclose(vq.embedding.weight.grad.cpu().numpy(), g["dW"], rtol=1e-5, atol=1e-6 * max(np.abs(g["dW"]).max(), 1e-30))
 
 
 @pytest.mark.parametrize("B,n_e,D,init", [(5000, 512, 256, "normal"), (5000, 512, 256, "ref"), (3001, 512, 128, "normal"),
@@ -150,11 +147,11 @@ def test_large_properties_and_determinism():
         (l1b + q1b.float().sum()).backward()
         assert torch.equal(g1, vq.embedding.weight.grad) and torch.equal(dz1, z.grad)
         vq.embedding.weight.grad = None
-        # codebook gradient vs a dense torch restatement
+        # codebook gradient vs a dense fp64 torch restatement (torch on the GPU as the checker)
         onehot = torch.zeros(B, n_e, device="cuda").scatter_(1, i1, 1.0)
         cnt = onehot.sum(0)
-        ref = 0.25 * 2.0 / (B * D) * (cnt[:, None] * vq.embedding.weight.detach() - onehot.t() @ z.detach().float())
-        torch.testing.assert_close(g1, ref, rtol=1e-3 if dt == torch.bfloat16 else 1e-4, atol=1e-7)
+        ref = 0.25 * 2.0 / (B * D) * (cnt.double()[:, None] * vq.embedding.weight.detach().double() - onehot.double().t() @ z.detach().double())
+        np.testing.assert_allclose(g1.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
 
 
 def test_errors_are_loud():
