@@ -115,3 +115,23 @@ def test_vgae_formulas_known_answers():
     # saturation: the literal +EPS form caps at -log(1e-15)
     lsat = ref_torch.recon_loss(torch.tensor([[40.0], [1.0]]), torch.tensor([[0], [1]]), torch.tensor([[0], [1]]))
     np.testing.assert_allclose(lsat.item(), 0.0 + -np.log(np.float32(1e-15)), rtol=1e-5)
+
+
+def test_mfma_bf16_step_model_reproduces_recorded_hardware_outputs():
+    """oracle_mfma_bf16_step8 (the restatement of v_mfma_f32_16x16x32_bf16's arithmetic the bf16 quantiser oracle is built
+    on) against outputs RECORDED on an MI355X by scripts/mfma_probe.hip (inputs: scripts/mfma_probe_gen*.py; fixture =
+    28 MFMAs x 256 dot products: random operands over exponent spreads 0..30, cancellation probes, quantiser-like data).
+    Every dot product must come out bit for bit (+0 == -0 allowed: the sign of an exact zero is not modelled)."""
+    from oracle import c_oracle
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "mfma_bf16_probe.npz"))
+    n = 0
+    for fam in ("random", "cancel", "vq"):
+        A, B, C, D = g[fam + "_A"], g[fam + "_B"], g[fam + "_C"], g[fam + "_D"]
+        for t in range(A.shape[0]):
+            for r in range(16):
+                for c in range(16):
+                    got = c_oracle.mfma_bf16_dot(A[t, r], B[t, c], float(C[t, r, c]))
+                    want = D[t, r, c]
+                    assert got.view(np.uint32) == want.view(np.uint32) or (got == 0 and want == 0), (fam, t, r, c, got, want)
+                    n += 1
+    assert n == 28 * 256
