@@ -96,6 +96,7 @@ struct CeegSpmmEx {
   int64_t val_stride = 1;         // element stride of val[] (2: one half of an interleaved pair)
   const int32_t* long_items = nullptr;  // (lo, hi, chunk*2+slot, row) pieces of the rows longer than the chunk (non-NULL: used INSTEAD of the scan)
   int64_t n_long_items = 0;
+  int nt = 0;                     // bit 0: non-temporal stores of out; bit 1: non-temporal loads of the col / val streams
   const int32_t* xidx = nullptr;  // row indirection for X (after the column map): gather X[xidx[c]] - X is then a small table
 };
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,

@@ -73,10 +73,11 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
   my_c = 0;
   my_v = 0.f;
   if (base + lane < p_hi) {
-    my_c = col[base + lane];
+    my_c = (ex.nt & 2) ? __builtin_nontemporal_load(col + base + lane) : col[base + lane];
     if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)ceeg_block_affine((int64_t)my_c, ex.col_a, ex.col_b, ex.mod);
     if (ex.xidx) my_c = ex.xidx[my_c];  // X is a table: node c's row is X[xidx[c]]
-    my_v = val[(int64_t)(vperm ? vperm[base + lane] : base + lane) * ex.val_stride];
+    const float* vp = val + (int64_t)(vperm ? vperm[base + lane] : base + lane) * ex.val_stride;
+    my_v = ((ex.nt & 2) && !vperm) ? __builtin_nontemporal_load(vp) : *vp;
   }
 }
 
@@ -293,7 +294,12 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         if (relu) {
           acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
         }
-        *reinterpret_cast<float4*>(o) = acc;
+        if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
+          __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
+          __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
+        } else {
+          *reinterpret_cast<float4*>(o) = acc;
+        }
       }
     }
     // publish draw it+2 (slot it&1 was last read two barriers ago), start the row-pointer load of row(it+2)
@@ -341,6 +347,90 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
   return CEEG_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------- gather probe
+// Measurement kernel (ceeg_spmm_gather_probe): the row kernel's traversal (per-XCD in-order queue, one wave per row, 64
+// column indices per lane-parallel load, 8 row gathers in flight) with everything but the gathers removed - no value stream,
+// no FMA chain, no epilogue, no output matrix.  What it takes is the empirical ceiling of ANY SpMM on this graph that
+// gathers whole feature rows through the cache hierarchy.  `mode` selects the entries gathered: bit 0 = near ones
+// (|col - row| <= window), bit 1 = far ones; the split shows how much of the time the time-local edges (which an LDS-staged
+// band could serve) and the hub edges (single-use rows from all over X) each account for.
+template <int LPR>
+__global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_gather_probe_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ X, int64_t ldx, int64_t N,
+    int F, int mode, int window, unsigned int* __restrict__ sink, unsigned int* __restrict__ queue) {
+  __shared__ unsigned int s_draw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const int64_t nnz = rowptr[N];
+  const int64_t r_begin = xcd == 0 ? 0 : row_lower_bound(rowptr, N, nnz * xcd / 8);
+  const int64_t r_end = xcd == 7 ? N : row_lower_bound(rowptr, N, nnz * (xcd + 1) / 8);
+  constexpr int G = 64 / LPR;
+  const int fl = lane % LPR, sub = lane / LPR;
+  const int foff = 4 * fl;
+  const bool fl_ok = foff < F;
+  unsigned int* q = queue + xcd * 32;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (;;) {
+    if (threadIdx.x == 0) s_draw = atomicAdd(q, (unsigned)SPMM_GRAB);
+    __syncthreads();
+    const int64_t r = r_begin + s_draw + wave;
+    __syncthreads();
+    if (r - wave >= r_end) break;
+    if (r >= r_end) continue;
+    const int p_lo = rowptr[r], p_hi = rowptr[r + 1];
+    if (p_hi - p_lo > SPMM_CHUNK) continue;  // hub rows: the real kernel takes them by pieces in a launch of its own
+    for (int base = p_lo; base < p_hi; base += 64) {
+      const int n = p_hi - base < 64 ? p_hi - base : 64;
+      int my_c = -1;
+      if (base + lane < p_hi) {
+        my_c = col[base + lane];
+        const int d = my_c - (int)r;
+        const bool near = (d < 0 ? -d : d) <= window;
+        if (!((mode & 1) && near) && !((mode & 2) && !near)) my_c = -1;  // filtered out: no gather
+      }
+      const int ns = (n + G - 1) / G;
+      for (int i0 = 0; i0 < ns; i0 += 8) {
+        uint4 x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int j = (i0 + k) * G + sub;
+          const int c = __shfl(my_c, j < 64 ? j : 63, 64);
+          x[k] = make_uint4(0, 0, 0, 0);
+          if (i0 + k < ns && j < n && c >= 0 && fl_ok) x[k] = *reinterpret_cast<const uint4*>(X + (int64_t)c * ldx + foff);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc.x ^= x[k].x; acc.y ^= x[k].y; acc.z ^= x[k].z; acc.w ^= x[k].w; }
+      }
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = acc.x;  // keeps the loads alive; practically never taken
+}
+
+}  // namespace
+
+extern "C" int ceeg_spmm_gather_probe(const int32_t* rowptr, const int32_t* col, const float* X, int64_t ldx, int64_t N, int64_t nnz,
+                                      int F, int mode, int window, void* ws, size_t ws_bytes, void* stream) {
+  if (N <= 0 || nnz < 0 || !rowptr || !col || !X || !ws) return CEEG_EINVAL;
+  if (F < 4 || F > 256 || (F % 4) != 0 || (ldx % 4) != 0 || ldx < F || !ceeg_aligned(X, 16)) return CEEG_EUNSUPPORTED;
+  if (ws_bytes < SPMM_QUEUE_BYTES + 256 || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  unsigned int* queue = static_cast<unsigned int*>(ws);
+  unsigned int* sink = queue + SPMM_QUEUE_BYTES / 4;
+  if (hipMemsetAsync(queue, 0, SPMM_QUEUE_BYTES, st) != hipSuccess) return CEEG_ELAUNCH;
+  const int lpr = lpr_for(F);
+  const dim3 grid(8 * SPMM_BLOCKS_PER_XCD), block(SPMM_WAVES * 64);
+  switch (lpr) {
+    case 64: hipLaunchKernelGGL(spmm_gather_probe_kernel<64>, grid, block, 0, st, rowptr, col, X, ldx, N, F, mode, window, sink, queue); break;
+    case 32: hipLaunchKernelGGL(spmm_gather_probe_kernel<32>, grid, block, 0, st, rowptr, col, X, ldx, N, F, mode, window, sink, queue); break;
+    case 16: hipLaunchKernelGGL(spmm_gather_probe_kernel<16>, grid, block, 0, st, rowptr, col, X, ldx, N, F, mode, window, sink, queue); break;
+    default: return CEEG_EUNSUPPORTED;
+  }
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+namespace {
 }  // namespace
 
 extern "C" size_t ceeg_spmm_ws_bytes(int64_t N, int64_t nnz, int F) {
@@ -384,12 +474,19 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
   return rc;
 }
 
+// measurement switch (read per call): CEEG_SPMM_NT bit 0 = non-temporal stores of `out`, bit 1 = non-temporal col/val loads
+static int spmm_nt_env() {
+  const char* e = getenv("CEEG_SPMM_NT");
+  return e ? atoi(e) : 0;
+}
+
 extern "C" int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                              const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
                              int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream) {
   CeegSpmmEx ex;
   ex.mod = N;
   ex.max_row_nnz = max_row_nnz;
+  ex.nt = spmm_nt_env();
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }
@@ -404,6 +501,7 @@ extern "C" int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, co
   CeegSpmmEx ex;
   ex.mod = N;
   ex.max_row_nnz = max_row_nnz;
+  ex.nt = spmm_nt_env();
   ex.long_items = n_long > 0 ? long_items : no_items;  // non-NULL: "the list is authoritative" (host pointer never read when empty)
   ex.n_long_items = n_long;
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,

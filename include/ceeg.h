@@ -151,6 +151,13 @@ int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* 
                         int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,
                         int64_t n_long, void* ws, size_t ws_bytes, void* stream);
 
+/* Measurement entry (no reference counterpart; used by bench.py / scripts/spmm_probe.py, never by the model): the SpMM row
+ * kernel's traversal with everything but the row gathers removed - no value stream, no FMAs, no epilogue, no output.  Its
+ * time is the empirical ceiling of a whole-row gather SpMM on this graph.  mode bit 0: gather the entries with
+ * |col - row| <= window, bit 1: the others (3 = all).  F % 4 == 0, F <= 256; ws: ceeg_spmm_ws_bytes(N, nnz, F) bytes. */
+int ceeg_spmm_gather_probe(const int32_t* rowptr, const int32_t* col, const float* X, int64_t ldx, int64_t N, int64_t nnz,
+                           int F, int mode, int window, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * A3+A4  VGAE.reparametrize + VGAE.kl_loss (upstream PyG; anchors: MAX_LOGSTD scripts/run.py:13,
  *        BaseCVAE.reparameterize scripts/models.py:38-43), fused in one pass.
