@@ -10,9 +10,10 @@ optimizer step (encode -> reparam+KL -> VQ -> decode with 1:1 negatives -> backw
 with every input already resident in HBM.  value = positive directed edges processed per second, whole job.
 Multi-GPU: one graph shard per rank (weak scaling), gradients averaged with one RCCL all-reduce per step.
 
-Extra (my own measurements, not the driver's contract): --workload vq (BASELINE.json configs[2]) and
---workload cvgae (configs[3]: conditional VGAE + VQ on 64 collated graphs x 100k edges per rank), --workload gat
-(next-row N1: GATConv forward + backward on the configs[1] graph).
+At N = 1 the default run appends, AFTER the headline's timed region, extra keys on the same JSON line: `vq_bf16` / `vq_f32`
+(BASELINE.json configs[2], MFMA and HBM fractions), `cvgae` (configs[3]), `other_negatives` (the same step with the other
+negative sampler: uniform negative_sampling when the headline ran the permutation-structured one) and, inside `roofline`,
+the pure-gather ceiling of the SpMM.  --no-extras skips them.  Stand-alone: --workload vq | cvgae | gat.
 """
 import argparse
 import json
@@ -46,24 +47,52 @@ def parse():
     ap.add_argument("--cond-dim", type=int, default=32)
     ap.add_argument("--vq-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (configs[2], configs[3], uniform negatives, gather ceiling)")
+    ap.add_argument("--negatives", default="sigma", choices=["sigma", "uniform"])
     return ap.parse_args()
 
 
+def host_threads():
+    """Threads the CPU baseline may use: the cores this process is allowed to run on.  On the GPU box a one-GPU job owns a
+    16-core share of a much larger machine (os.cpu_count() reports the machine; OMP_NUM_THREADS / the affinity mask report
+    the share), so the smallest of the three is the honest count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        n = min(n, int(env))
+    return n
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
 def cpu_baseline(args):
-    """Oracle (CPU restatement, kind "port") timed on this box's host cores on a 1/16 sample of the workload."""
+    """Oracle (CPU restatement, kind "port") timed on this box's host cores on an N/8, E/8 sample of the workload
+    (same generator and seeds, all available cores, 1 warm-up + best of 3, CPU model stated)."""
     from oracle import ref_torch  # checker / reported baseline only
     from causal_eeg_vae_amd.synth import synth_event_graph, synth_features
-    threads = min(os.cpu_count() or 1, 16)
+    threads = host_threads()
     torch.set_num_threads(threads)
-    n, e = args.nodes // 16, args.edges // 16
-    ei = synth_event_graph(n, e, seed=0)
-    x = synth_features(n, args.in_dim, seed=0)
+    n, e = args.nodes // 8, args.edges // 8
+    ei = synth_event_graph(n, e, seed=1000)
+    x = synth_features(n, args.in_dim, seed=1000)
     torch.manual_seed(0)
     model = ref_torch.RefVGAEVQ(args.in_dim, args.latent, args.codes, 0.25)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     gen = torch.Generator().manual_seed(1)
     best = float("inf")
-    for it in range(3):
+    for it in range(4):
         eps = torch.randn(n, args.latent, generator=gen)
         neg = torch.randint(0, n, (2, e), generator=gen)
         t0 = time.perf_counter()
@@ -75,7 +104,98 @@ def cpu_baseline(args):
         if it > 0:
             best = min(best, dt)
     return {"value": e / best, "unit": "edges/s", "cores": threads, "kind": "port",
-            "sample": f"oracle/ref_torch.RefVGAEVQ full step (fwd+bwd+Adam), {n} nodes / {e} edges (1/16 of the workload), best of 2 after 1 warm-up"}
+            "sample": f"oracle/ref_torch.RefVGAEVQ full step (fwd+bwd+Adam, stock PyTorch CPU ops, fp32) on {cpu_model()}, {threads} threads "
+                      f"(machine reports {os.cpu_count()}), {n} nodes / {e} edges (1/8 of the workload, same generator), best of 3 after 1 warm-up"}
+
+
+def run_vq(dev, dtype_name, steps, warmup, rank=0, world=1, barrier=None):
+    """BASELINE.json configs[2]: VectorQuantizer forward, 4 Mi latents x 512 codes x 256-d.  Reports BOTH roofline fractions
+    (in bf16 the kernel sits at the ridge): MFMA flops 2 B n_e D against the dense peak, and the
+    compulsory HBM bytes B (2 D s + 8) + n_e D 4 against 8 TB/s."""
+    from causal_eeg_vae_amd import VectorQuantizer
+    B, n_e, D = 4 * 1024 * 1024, 512, 256
+    dt = torch.bfloat16 if dtype_name == "bf16" else torch.float32
+    torch.manual_seed(rank)
+    z = torch.randn(B, D, device=dev).to(dt)
+    vq = VectorQuantizer(n_e, D, 0.25, return_one_hot=False).to(dev)
+    sync = barrier or torch.cuda.synchronize
+    with torch.no_grad():
+        vq.embedding.weight.normal_()
+        for _ in range(warmup):
+            vq(z)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            vq(z)
+        sync()
+    el = time.perf_counter() - t0
+    ms = el / steps * 1e3
+    flops = 2.0 * B * n_e * D
+    peak = MFMA_BF16_PEAK_TF if dt == torch.bfloat16 else MFMA_F32_PEAK_TF
+    es = 2 if dt == torch.bfloat16 else 4
+    hbm_bytes = B * (2 * D * es + 8) + n_e * D * 4
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"ms": ms, "latents_per_s": B * world / (el / steps), "TFLOP/s": tf, "mfma_peak_TFLOP/s": peak, "mfma_frac": tf / peak,
+            "compulsory_GB": hbm_bytes / 1e9, "hbm_GB/s": hbm_bytes / (ms * 1e-3) / 1e9, "hbm_frac": hbm_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "shape": f"{B}x{n_e}x{D}", "dtype": dtype_name}
+
+
+def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
+    """BASELINE.json configs[3]: conditional GCN-VGAE + VQ on a collated batch of graphs per rank."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ, EventGraph
+    from causal_eeg_vae_amd.synth import collate_graphs, synth_event_graph, synth_features
+    from causal_eeg_vae_amd.trainer import Trainer
+    G, n, e, C = args.graphs, args.nodes_per_graph, args.edges_per_graph, args.cond_dim
+    eis = [synth_event_graph(n, e, seed=(1000 + rank) * 4096 + g, device=dev) for g in range(G)]
+    ei, batch, N = collate_graphs(eis, [n] * G)
+    x = synth_features(N, args.in_dim, seed=1000 + rank, device=dev)
+    gen = torch.Generator(device=dev).manual_seed(77 + rank)
+    cond = torch.randn(G, C, generator=gen, device=dev)
+    graph = EventGraph(ei, N)
+    graph.dec
+    torch.manual_seed(0)
+    model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
+    with torch.no_grad():
+        model.vector_quantization.embedding.weight.normal_(0, 0.1)
+    trainer = Trainer(model, lr=1e-3, world_size=world)
+    sync = barrier or torch.cuda.synchronize
+    for _ in range(warmup):
+        trainer.step(x, graph, batch, cond, nodes_per_graph=n)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss, aux = trainer.step(x, graph, batch, cond, nodes_per_graph=n)
+    sync()
+    el = time.perf_counter() - t0
+    return el, float(loss.item()), (f"conditional GCN-VGAE+VQ train step, {G} collated graphs x {e} edges x {n} nodes per GPU, in {args.in_dim}+{C}, "
+                                    f"latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 permutation-structured negatives, Adam")
+
+
+def gather_ceiling_ms(graph, x_like, F):
+    """The pure-gather probe (ceeg_spmm_gather_probe) on the two structures the F-wide roofline launches walk (forward CSR and
+    its transpose), median of 7 launches each, plus the measured hub-piece launch of the transposed pass: the empirical
+    ceiling of a whole-row gather SpMM on this graph."""
+    from causal_eeg_vae_amd import _lib
+    L = _lib.lib()
+    p = graph.gcn
+    N = graph.num_nodes
+    x = torch.randn(N, F, device=x_like.device)
+    ws = _lib.workspace(L.ceeg_spmm_ws_bytes(N, p.nnz, F) + 4096, x.device)
+    out = []
+    for rp, col in ((p.rowptr, p.col), (p.t_rowptr, p.t_col)):
+        ts = []
+        for it in range(10):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            _lib.check(L.ceeg_spmm_gather_probe(rp.data_ptr(), col.data_ptr(), x.data_ptr(), x.stride(0), N, p.nnz, F, 3, 64, ws.data_ptr(),
+                                                ws.numel(), _lib.stream()), "ceeg_spmm_gather_probe")
+            e.record()
+            torch.cuda.synchronize()
+            if it >= 3:
+                ts.append(s.elapsed_time(e))
+        ts.sort()
+        out.append(ts[len(ts) // 2])
+    return out
 
 
 def main():
@@ -118,30 +238,13 @@ def main():
             torch.cuda.synchronize()
 
     if args.workload == "vq":
-        B, n_e, D = 4 * 1024 * 1024, 512, 256
-        dt = torch.bfloat16 if args.vq_dtype == "bf16" else torch.float32
-        torch.manual_seed(rank)
-        z = torch.randn(B, D, device=dev).to(dt)
-        vq = VectorQuantizer(n_e, D, 0.25, return_one_hot=False).to(dev)
-        with torch.no_grad():
-            vq.embedding.weight.normal_()
-            for _ in range(args.warmup):
-                vq(z)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                vq(z)
-            barrier()
-        el = time.perf_counter() - t0
-        flops = 2.0 * B * n_e * D
-        ms = el / args.steps * 1e3
-        peak = MFMA_BF16_PEAK_TF if dt == torch.bfloat16 else MFMA_F32_PEAK_TF
-        print(json.dumps({"metric": "VQ forward latents/s", "value": B * world / (el / args.steps), "unit": "latents/s", "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        r = run_vq(dev, args.vq_dtype, args.steps, args.warmup, rank, world, barrier)
+        print(json.dumps({"metric": "VQ forward latents/s", "value": r["latents_per_s"], "unit": "latents/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms"], "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": args.vq_dtype, "data": "synthetic",
-                          "config": {"workload": f"VectorQuantizer fwd {B}x{n_e}x{D}"},
-                          "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                       "frac": flops / (ms * 1e-3) / 1e12 / peak, "traffic": None}}))
+                          "config": {"workload": f"VectorQuantizer fwd {r['shape']}"},
+                          "roofline": {"bound": "mfma", "achieved": r["TFLOP/s"], "peak": r["mfma_peak_TFLOP/s"], "unit": "TFLOP/s",
+                                       "frac": r["mfma_frac"], "traffic": None, "hbm_frac": r["hbm_frac"], "hbm_GB/s": r["hbm_GB/s"]}}))
         return
 
     if args.workload == "gat":
@@ -179,41 +282,18 @@ def main():
         return
 
     if args.workload == "cvgae":
-        from causal_eeg_vae_amd import ConditionalVGAEVQ
-        from causal_eeg_vae_amd.synth import collate_graphs
-        G, n, e, C = args.graphs, args.nodes_per_graph, args.edges_per_graph, args.cond_dim
-        eis = [synth_event_graph(n, e, seed=(1000 + rank) * 4096 + g, device=dev) for g in range(G)]
-        ei, batch, N = collate_graphs(eis, [n] * G)
-        x = synth_features(N, args.in_dim, seed=1000 + rank, device=dev)
-        gen = torch.Generator(device=dev).manual_seed(77 + rank)
-        cond = torch.randn(G, C, generator=gen, device=dev)
-        graph = EventGraph(ei, N)
-        graph.dec
-        torch.manual_seed(0)
-        model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
-        with torch.no_grad():
-            model.vector_quantization.embedding.weight.normal_(0, 0.1)
-        trainer = Trainer(model, lr=1e-3, world_size=world)
-        for _ in range(args.warmup):
-            trainer.step(x, graph, batch, cond, nodes_per_graph=n)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            loss, aux = trainer.step(x, graph, batch, cond, nodes_per_graph=n)
-        barrier()
-        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
         if world > 1:
             if backend != "nccl":
                 t = t.cpu()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         if rank == 0:
-            print(json.dumps({"metric": "VGAE train edges/sec", "value": G * e * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+            print(json.dumps({"metric": "VGAE train edges/sec", "value": args.graphs * args.edges_per_graph * world / (el / args.steps), "unit": "edges/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"conditional GCN-VGAE+VQ train step, {G} collated graphs x {e} edges x {n} nodes per GPU, "
-                                                     f"in {args.in_dim}+{C}, latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 negatives, Adam",
-                                         "parallelism": f"dp{world}"}, "loss": float(loss.item())}))
+                              "config": {"workload": wl, "parallelism": f"dp{world}"}, "loss": last_loss}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -224,7 +304,7 @@ def main():
     graph = EventGraph(ei, N)
     graph.dec  # build the decoder structure before timing
     torch.manual_seed(0)
-    model = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank).to(dev)
+    model = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank, negatives=args.negatives).to(dev)
     with torch.no_grad():
         model.vector_quantization.embedding.weight.normal_(0, 0.1)
     note("graph built")
@@ -260,26 +340,58 @@ def main():
         spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * F * 4
         launches, spmm_ms = prof.get(f"spmm_F{F}", (0, float("nan")))  # layer-2 aggregation (fwd) and its transposed pass (bwd)
         achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-        # HBM-side bytes per launch from the rocprofv3 PMC passes of this round (profiles/r01_step_pmc_hbm.txt);
+        # HBM-side bytes per launch from the rocprofv3 PMC passes of this round (profiles/r02_spmm_bound.txt);
         # counters cannot be read from inside the process, so the figure is reported only for the workload it was
         # measured on
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_spmm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_spmm_traffic.json")
         if os.path.exists(tpath):
             t = json.load(open(tpath))
             if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F):
                 traffic = t["traffic_bytes"]
+        neg_label = ("1:1 permutation-structured negatives (sigma affine per step, pairs colliding with an edge masked)" if args.negatives == "sigma"
+                     else "1:1 uniform negatives (negative_sampling: ceeg_neg_sample_uniform per step, per-step CSR of the samples)")
         line = {"metric": "VGAE train edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"GCN-VGAE+VQ train step, synthetic power-law event graph {N} nodes / {E} edges per GPU, "
-                                       f"in {args.in_dim}, latent {args.latent}, {args.codes} codes, 1:1 negatives, Adam",
+                                       f"in {args.in_dim}, latent {args.latent}, {args.codes} codes, {neg_label}, Adam",
                            "parallelism": f"dp{world}"},
                 "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr F={F} (spmm_rows_kernel<64> + long-row pieces)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": traffic, "launches_timed": launches, "avg_launch_ms": spmm_ms,
                              "algorithmic_bytes_per_launch": spmm_bytes},
                 "loss": float(loss.item())}
+        if world == 1 and not args.no_extras:
+            # Extra legs, after the headline's timed region (BASELINE metric = "edges/s; SpMM HBM GB/s; VQ MFMA util"):
+            # (1) the empirical ceiling of the roofline kernel: the same traversal with only the row gathers left
+            fwd_c, tr_c = gather_ceiling_ms(graph, x, F)
+            hub_ms = prof.get(f"spmm_F{F}", (0, 0.0))[1]
+            line["roofline"]["gather_only_ms"] = {"forward": fwd_c, "transposed_rows_le_256": tr_c}
+            line["roofline"]["launch_ms_over_gather_only_ms"] = spmm_ms / ((fwd_c + tr_c) / 2)
+            # (2) the literal sampler path of the north star on the same graph: negative_sampling per step
+            del trainer
+            model_u = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank, negatives="uniform" if args.negatives == "sigma" else "sigma").to(dev)
+            model_u.load_state_dict(model.state_dict())
+            tr_u = Trainer(model_u, lr=1e-3, world_size=1)
+            for _ in range(2):
+                tr_u.step(x, graph)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                lu, _ = tr_u.step(x, graph)
+            torch.cuda.synchronize()
+            ms_u = (time.perf_counter() - t1) / 5 * 1e3
+            line["other_negatives"] = {"negatives": model_u.negatives, "ms_per_step": ms_u, "edges_per_s": E / (ms_u * 1e-3), "steps": 5, "loss": float(lu.item())}
+            del tr_u, model_u, graph, model
+            torch.cuda.empty_cache()
+            # (3) BASELINE.json configs[2] (VQ 4 Mi x 512 x 256) in both dtypes and configs[3] (64 collated graphs x 100k edges)
+            line["vq_bf16"] = run_vq(dev, "bf16", 20, 3)
+            line["vq_f32"] = run_vq(dev, "f32", 10, 2)
+            torch.cuda.empty_cache()
+            el_c, loss_c, wl_c = run_cvgae(args, dev, 20, 3)
+            line["cvgae"] = {"ms_per_step": el_c / 20 * 1e3, "edges_per_s": args.graphs * args.edges_per_graph / (el_c / 20), "steps": 20,
+                             "workload": wl_c, "loss": loss_c}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(line))

@@ -42,7 +42,7 @@ SIGNATURES = {
     "ceeg_reparam_vq_bwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _vp, _vp, _vp, _vp, _c_int, _vp, _vp, _c_i64, _c_int, _c_f32, _c_int,
                                      _c_int, _vp, _c_i64, _vp, _c_i64, _vp, _vp, _c_sz, _vp]),
     "ceeg_edge_bce_ws_bytes": (_c_sz, [_c_i64, _c_int]),
-    "ceeg_edge_bce_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_edge_bce_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_decoder_fused_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
     "ceeg_decoder_fused_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_int, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_decoder_fused_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_int, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _c_sz, _vp]),

@@ -74,8 +74,9 @@ __global__ __launch_bounds__(1024) void dec_finalize_kernel(const float* __restr
 // ------------------------------------------------------------------ edge-list form (any order)
 template <int LPR>
 __global__ __launch_bounds__(DEC_WAVES * 64) void edge_bce_fwd_kernel(
-    const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int D,
-    int negative, float* __restrict__ coef, float* __restrict__ prob, float* __restrict__ part) {
+    const float* __restrict__ z, int64_t ldz, const int32_t* __restrict__ zidx, const int32_t* __restrict__ ei,
+    const int32_t* __restrict__ ej, int64_t E, int D, int negative, float* __restrict__ coef, float* __restrict__ prob,
+    float* __restrict__ part) {
   __shared__ float red[3 * DEC_WAVES];
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
@@ -83,26 +84,32 @@ __global__ __launch_bounds__(DEC_WAVES * 64) void edge_bce_fwd_kernel(
   const bool fl_ok = 4 * fl < D;
   const int64_t wave = (int64_t)blockIdx.x * DEC_WAVES + (threadIdx.x >> 6);
   const int64_t nwaves = (int64_t)gridDim.x * DEC_WAVES;
-  float acc = 0.f;
+  float acc = 0.f, cnt = 0.f;
   for (int64_t e0 = wave * G; e0 < E; e0 += nwaves * G) {
     const int64_t e = e0 + sub;
-    const bool ok = e < E;
+    int ni = -1, nj = -1;
+    if (e < E) { ni = ei[e]; nj = ej[e]; }
+    const bool ok = ni >= 0 && nj >= 0;  // a pair with a negative id is a sample the sampler gave up on: skipped
     float d = 0.f;
     if (ok && fl_ok) {
-      const float4 a = *reinterpret_cast<const float4*>(z + (int64_t)ei[e] * ldz + 4 * fl);
-      const float4 b = *reinterpret_cast<const float4*>(z + (int64_t)ej[e] * ldz + 4 * fl);
+      if (zidx) { ni = zidx[ni]; nj = zidx[nj]; }  // quantised latent: node n's row is z[zidx[n]] (z = the codebook)
+      const float4 a = *reinterpret_cast<const float4*>(z + (int64_t)ni * ldz + 4 * fl);
+      const float4 b = *reinterpret_cast<const float4*>(z + (int64_t)nj * ldz + 4 * fl);
       d = dot4(a, b);
     }
     d = group_sum<LPR>(d);
-    if (ok && fl == 0) {
-      float t, c;
-      if (negative) dec_neg(d, t, c); else dec_pos(d, t, c);
+    if (e < E && fl == 0) {
+      float t = 0.f, c = 0.f;
+      if (ok) {
+        if (negative & 1) dec_neg(d, t, c); else dec_pos(d, t, c);
+        cnt += 1.0f;
+      }
       if (coef) coef[e] = c;
-      if (prob) prob[e] = dec_sigmoid(d);
+      if (prob) prob[e] = ok ? ((negative & 2) ? d : dec_sigmoid(d)) : 0.f;  // bit 1: the raw inner product (sigmoid=False)
       acc += t;
     }
   }
-  dec_block_out(acc, 0.f, 0.f, red, part);
+  dec_block_out(acc, cnt, 0.f, red, part);
 }
 
 // ------------------------------------------------------------------ fused CSR form, permutation-structured negatives
@@ -818,8 +825,8 @@ extern "C" size_t ceeg_edge_bce_ws_bytes(int64_t E, int D) {
   return ceeg_ws_part((size_t)DEC_MAX_BLOCKS * 3, 4);
 }
 
-extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32_t* j, int64_t E, int D,
-                                 int negative, float* coef, float* prob, float* loss_sum,
+extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* i, const int32_t* j, int64_t E,
+                                 int D, int negative, float* coef, float* prob, float* loss_sum,
                                  void* ws, size_t ws_bytes, void* stream) {
   if (!z || !loss_sum || E < 0 || D <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
   if ((D % 4) != 0 || D > 256 || (ldz % 4) != 0 || ldz < D) return CEEG_EUNSUPPORTED;
@@ -834,7 +841,7 @@ extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, 
   const int nblk = (int)(nb < DEC_MAX_BLOCKS ? nb : DEC_MAX_BLOCKS);
 #define CEEG_EDGE_CASE(L)                                                                                                              \
   case L:                                                                                                                              \
-    hipLaunchKernelGGL(edge_bce_fwd_kernel<L>, dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, i, j, E, D, negative, coef, prob, part); \
+    hipLaunchKernelGGL(edge_bce_fwd_kernel<L>, dim3(nblk), dim3(DEC_WAVES * 64), 0, st, z, ldz, zidx, i, j, E, D, negative, coef, prob, part); \
     break;
   switch (lpr) {
     CEEG_EDGE_CASE(1)
@@ -848,7 +855,7 @@ extern "C" int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, 
   }
 #undef CEEG_EDGE_CASE
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, 1, loss_sum);
+  hipLaunchKernelGGL(dec_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nblk, 2, loss_sum);  // [sum of terms, pairs counted]
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

@@ -123,6 +123,12 @@ class EventGraph:
         self.gcn.long_items(False), self.gcn.long_items(True)  # piece lists of the hub rows: graph-construction work
         self._dec = None
 
+    def edge_index_i32(self):
+        """int32 copy of edge_index for the edge-list kernels (made once per graph)."""
+        if getattr(self, "_ei32", None) is None:
+            self._ei32 = self.edge_index.to(torch.int32).contiguous()
+        return self._ei32
+
     @property
     def dec(self):
         if self._dec is None:
@@ -183,22 +189,20 @@ def _relu_bwd_colsum(g, y):
     return gm, out
 
 
-# Column sums a producer kernel already holds for a gradient tensor it is about to hand to autograd (the fused
-# reparam + VQ backward leaves the head's bias gradient): keyed by the tensor's storage pointer, consumed once.
-_COLSUM_HINT = {}
-
-
+# Column sums a producer kernel already holds for a gradient tensor it hands to autograd (the fused reparam + VQ backward
+# leaves the encoder head's bias gradient).  The hint rides ON the gradient tensor itself (an attribute of the tensor object,
+# which autograd carries to the consuming node) together with the tensor's version counter: if autograd accumulates a second
+# gradient into the buffer (in place: the version moves; out of place: a new tensor without the attribute) or a hook edits
+# it, the hint no longer matches and the consumer recomputes the column sums.  No module-level state.
 def _offer_colsum(t, colsum):
-    import weakref
-    _COLSUM_HINT.clear()
-    _COLSUM_HINT[t.data_ptr()] = (weakref.ref(t), tuple(t.shape), colsum)
+    t._ceeg_colsum = (colsum, t._version, tuple(t.shape))
 
 
 def _take_colsum(t):
-    ent = _COLSUM_HINT.pop(t.data_ptr(), None)
-    if ent is None or ent[0]() is None or ent[1] != tuple(t.shape) or not t.is_contiguous():
+    ent = getattr(t, "_ceeg_colsum", None)
+    if ent is None or ent[1] != t._version or ent[2] != tuple(t.shape) or not t.is_contiguous():
         return None
-    return ent[2]
+    return ent[0]
 
 
 class _GcnAggregate(torch.autograd.Function):
@@ -406,11 +410,12 @@ class _ReparamVQ(torch.autograd.Function):
                    "ceeg_vq_forward")
         ctx.save_for_backward(ml, epsc, wc, idx, z)
         ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
-        ctx.mark_non_differentiable(scal[1], idx)
+        loss_t, ppl_t = scal[0], scal[1]
+        ctx.mark_non_differentiable(ppl_t, idx)
         # an output nobody differentiates (z in the training step) must not come back as an [N, D] tensor of zeros: that is a
         # 0.5 GB fill plus a 0.5 GB read inside the fused backward; the backward takes None for it
         ctx.set_materialize_grads(False)
-        return z, kl, scal[0], z_q, scal[1], idx
+        return z, kl, loss_t, z_q, ppl_t, idx
 
     @staticmethod
     def backward(ctx, g_z, g_kl, g_loss, g_zq, _g_ppl, _g_idx):
@@ -463,10 +468,13 @@ def _edge_lists_i32(edge_index):
 
 
 class _EdgeBCE(torch.autograd.Function):
-    """sum_e term_e over an arbitrary edge list; backward = two SpMMs over the list's CSR and transpose."""
+    """(sum_e term_e, number of pairs counted) over an arbitrary edge list; backward = two SpMMs over the list's CSR and
+    transpose.  Pairs with a negative id (samples the sampler gave up on) are skipped.  table / table_idx: a quantised
+    latent given as (codebook, int32 code per node) with z[n] == table[table_idx[n]] bit for bit - the forward then gathers
+    codebook rows (L2-resident) through the 4-byte index; the backward's SpMMs gather rows of `z` itself."""
 
     @staticmethod
-    def forward(ctx, z, edge_index, negative, pair):
+    def forward(ctx, z, edge_index, negative, pair, table=None, table_idx=None):
         _lib.require_cuda(z, edge_index)
         L = _lib.lib()
         z = z.contiguous()
@@ -474,59 +482,70 @@ class _EdgeBCE(torch.autograd.Function):
         i, j = _edge_lists_i32(edge_index)
         E = i.shape[0]
         coef = torch.empty(max(E, 1), dtype=torch.float32, device=z.device)[:E]
-        out = torch.zeros((), dtype=torch.float32, device=z.device)
+        out = torch.zeros(2, dtype=torch.float32, device=z.device)
         ws = _lib.workspace(L.ceeg_edge_bce_ws_bytes(E, D), z.device)
-        _lib.check(L.ceeg_edge_bce_fwd(z.data_ptr(), z.stride(0), i.data_ptr(), j.data_ptr(), E, D, int(negative), coef.data_ptr(),
-                                       None, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
+        src, sidx = (z, None) if table is None else (table.detach().contiguous(), table_idx.contiguous())
+        with _lib.timed("edge_bce_fwd"):
+            _lib.check(L.ceeg_edge_bce_fwd(src.data_ptr(), src.stride(0), _lib.ptr(sidx), i.data_ptr(), j.data_ptr(), E, D, int(negative),
+                                           coef.data_ptr(), None, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
         ctx.save_for_backward(z, coef)
         ctx.edge_index, ctx.pair = edge_index, pair
-        return out
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _gc):
         z, coef = ctx.saved_tensors
         N = z.shape[0]
-        pair = ctx.pair if ctx.pair is not None else CsrPair(ctx.edge_index, N, self_loops=False)
+        # the CSR of a fresh edge list (sampled negatives) is built here, once per step: a stable sort by (dst, src) on the
+        # device; skipped pairs (negative ids) carry coef 0, so any in-range endpoint will do for them
+        pair = ctx.pair if ctx.pair is not None else CsrPair(ctx.edge_index.clamp(min=0), N, self_loops=False)
         # CSR rows = edge_index[1] (j), cols = edge_index[0] (i); perm maps CSR position -> edge id
         cv = coef[pair.perm.long()] * g
         dz = _spmm(pair.rowptr, pair.col, cv, None, z, N, max_row=pair.max_row)
         _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True, max_row=pair.max_trow)
-        return dz, None, None, None
+        return dz, None, None, None, None, None
 
 
 class InnerProductDecoder(nn.Module):
-    """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge."""
+    """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge (sigmoid=False: the raw inner product).  Inference-only: it
+    carries no autograd path - training goes through VGAE.recon_loss, whose loss and gradient are fused kernels."""
 
     def forward(self, z, edge_index, sigmoid=True):
         _lib.require_cuda(z, edge_index)
         L = _lib.lib()
-        zc = z.contiguous()
+        zc = z.detach().contiguous()
         i, j = _edge_lists_i32(edge_index)
         E, D = i.shape[0], zc.shape[1]
         prob = torch.empty(max(E, 1), dtype=torch.float32, device=z.device)[:E]
-        out = torch.zeros((), dtype=torch.float32, device=z.device)
+        out = torch.zeros(2, dtype=torch.float32, device=z.device)
         ws = _lib.workspace(L.ceeg_edge_bce_ws_bytes(E, D), z.device)
-        _lib.check(L.ceeg_edge_bce_fwd(zc.data_ptr(), zc.stride(0), i.data_ptr(), j.data_ptr(), E, D, 0, None, prob.data_ptr(),
-                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
-        return prob if sigmoid else torch.logit(prob)
+        _lib.check(L.ceeg_edge_bce_fwd(zc.data_ptr(), zc.stride(0), None, i.data_ptr(), j.data_ptr(), E, D, 0 if sigmoid else 2, None,
+                                       prob.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
+        return prob
 
     def forward_all(self, z, sigmoid=True):
         adj = z @ z.t()  # dense N x N: small graphs only (out of scope at N = 1M, SURVEY.md §8 A6)
         return torch.sigmoid(adj) if sigmoid else adj
 
 
+def negative_sampling_raw(graph_or_pair, num_nodes, num, seed):
+    """ceeg_neg_sample_uniform: int32 [2, num] on the device, (-1, -1) where 16 attempts all collided.  No host sync."""
+    L = _lib.lib()
+    pair = graph_or_pair.dec if isinstance(graph_or_pair, EventGraph) else graph_or_pair
+    out = torch.empty(2, max(int(num), 1), dtype=torch.int32, device=pair.device)[:, : int(num)]
+    _lib.check(L.ceeg_neg_sample_uniform(pair.rowptr.data_ptr(), pair.col.data_ptr(), int(num_nodes), int(num), int(seed), out[0].data_ptr(),
+                                         out[1].data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform")
+    return out
+
+
 def negative_sampling(edge_index, num_nodes, num_neg_samples=None, seed=0, graph=None):
     """Uniform negative sampler (PyG negative_sampling surface).  Deterministic under `seed`
     (Philox4x32-10, restated in oracle/ceeg_oracle.c); samples that collide 16 times are dropped."""
     _lib.require_cuda(edge_index)
-    L = _lib.lib()
     pair = graph.dec if isinstance(graph, EventGraph) else CsrPair(edge_index, num_nodes, self_loops=False)
     num = int(edge_index.shape[1] if num_neg_samples is None else num_neg_samples)
-    s = torch.empty(max(num, 1), dtype=torch.int32, device=edge_index.device)[:num]
-    d = torch.empty(max(num, 1), dtype=torch.int32, device=edge_index.device)[:num]
-    _lib.check(L.ceeg_neg_sample_uniform(pair.rowptr.data_ptr(), pair.col.data_ptr(), num_nodes, num, int(seed), s.data_ptr(),
-                                         d.data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform")
-    out = torch.stack([s, d]).to(torch.int64)
+    out = negative_sampling_raw(pair, num_nodes, num, seed).to(torch.int64)
     return out[:, out[0] >= 0]
 
 
@@ -720,11 +739,11 @@ class VGAE(nn.Module):
         N = z.shape[0]
         pos_pair = graph.dec if isinstance(graph, EventGraph) else None
         E = pos_edge_index.shape[1]
-        pos = _EdgeBCE.apply(z, pos_edge_index, False, pos_pair) / max(E, 1)
+        ps, pc = _EdgeBCE.apply(z, pos_edge_index, False, pos_pair)
         if neg_edge_index is None:
             neg_edge_index = negative_sampling(pos_edge_index, N, seed=self.seed + self._step, graph=graph)
-        neg = _EdgeBCE.apply(z, neg_edge_index, True, None) / max(neg_edge_index.shape[1], 1)
-        return pos + neg
+        ns, nc = _EdgeBCE.apply(z, neg_edge_index, True, None)
+        return ps / pc.clamp(min=1.0) + ns / nc.clamp(min=1.0)
 
 
 class VGAEVQ(nn.Module):
@@ -736,24 +755,43 @@ class VGAEVQ(nn.Module):
         loss = rec + kl / N + vq_loss                                   (loss sum as scripts/run.py:95)
     """
 
-    def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0):
+    def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0, negatives="sigma"):
+        """negatives: "sigma" = permutation-structured negatives (col[p], sigma(r)) drawn inside the fused decoder (no per-step
+        sort; colliding pairs masked) - the fast path; "uniform" = the literal recon_loss path: E pairs from
+        negative_sampling (ceeg_neg_sample_uniform, rejection against the edge set) decoded through the edge-list kernel,
+        their per-step CSR built by a device sort for the atomics-free backward."""
         super().__init__()
+        if negatives not in ("sigma", "uniform"):
+            raise ValueError("negatives must be 'sigma' or 'uniform'")
         self.encoder = VariationalGCNEncoder(in_channels, latent)
         self.vector_quantization = VectorQuantizer(num_latent_embeddings, latent, beta, return_one_hot=False)
-        self.latent, self.seed = latent, int(seed)
+        self.latent, self.seed, self.negatives = latent, int(seed), negatives
 
-    def forward(self, x, graph, step=0, eps=None, sigma=None):
+    def negative_seed(self, step):
+        return (self.seed * 0x9E3779B1 + 0x5851F42D * (int(step) + 1)) & (2**63 - 1)
+
+    def forward(self, x, graph, step=0, eps=None, sigma=None, neg_edge_index=None):
         N = x.shape[0]
         ml = self.encoder.forward_fused(x, graph)
         D = self.latent
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
         z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, seed, self.training, self.vector_quantization)
-        a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
-        # z_q is bit-for-bit codebook[idx] in fp32: let the decoder gather 512 codebook rows through idx
-        rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, None, self.vector_quantization.embedding.weight,
-                                        idx.view(-1).to(torch.int32))
+        if self.negatives == "uniform" or neg_edge_index is not None:
+            # literal path: recon_loss(z_q, pos_edge_index, negative_sampling(...)) - one fresh sample set per step
+            if neg_edge_index is None:
+                neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
+            W, code = self.vector_quantization.embedding.weight, idx.view(-1).to(torch.int32)
+            ps, pc = _EdgeBCE.apply(z_q, graph.edge_index_i32(), False, graph.dec, W, code)
+            ns, nc = _EdgeBCE.apply(z_q, neg_edge_index, True, None, W, code)
+            rec = ps / pc.clamp(min=1.0) + ns / nc.clamp(min=1.0)
+            sums = torch.stack([ps.detach(), ns.detach(), nc])
+        else:
+            a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma
+            # z_q is bit-for-bit codebook[idx] in fp32: let the decoder gather 512 codebook rows through idx
+            rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, None, self.vector_quantization.embedding.weight,
+                                            idx.view(-1).to(torch.int32))
         loss = rec + kl / N + vq_loss
-        return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
+        return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums, neg_edge_index=neg_edge_index)
 
 
 class ConditionalVGAEVQ(nn.Module):

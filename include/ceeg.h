@@ -195,14 +195,16 @@ int ceeg_reparam_vq_bwd(const float* mu, int64_t ld_mu, const float* logstd, int
 /* ------------------------------------------------------------------------------------------------
  * A6  InnerProductDecoder.forward + GAE.recon_loss (upstream PyG), literal "+EPS" form, EPS = 1e-15:
  *   v_e = <z[i_e], z[j_e]> ; pos: -log(sigmoid(v)+EPS) ; neg: -log(1-sigmoid(v)+EPS)
- * Edge-list form (any edge order; used for user-supplied pos/neg edge_index):
- *   i,j: [E] int32 node ids.  negative != 0 selects the neg term.  Outputs: coef[e] = d(term_e)/dv_e
- *   (fp32, unscaled), loss_sum: 1 float (device) = sum_e term_e  (the caller divides by E: mean),
+ * Edge-list form (any edge order; used for user-supplied pos/neg edge_index and for sampled negatives):
+ *   i,j: [E] int32 node ids; a pair with a negative id (a sample ceeg_neg_sample_uniform gave up on) is SKIPPED: term 0,
+ *   coef 0, not counted.  negative bit 0 selects the neg term; bit 1 makes prob[e] the raw inner product v_e.  Outputs: coef[e] = d(term_e)/dv_e (fp32, unscaled),
+ *   loss_sum: TWO floats (device) = { sum_e term_e, number of pairs counted }  (the caller divides: mean),
  *   optionally prob[e] = sigmoid(v_e) (decoder(z, edge_index, sigmoid=True)).
+ *   zidx (int32 [N] or NULL): quantised latent - node n's row is z[zidx[n]] and `z` is the codebook (as in the fused form).
  * The backward  dz[n] = sum_{e: i_e=n} c_e z[j_e] + sum_{e: j_e=n} c_e z[i_e]  is two ceeg_spmm_csr calls
  * over the edge list's CSR and its transpose (val = coef via perm) — atomics-free by construction. */
 size_t ceeg_edge_bce_ws_bytes(int64_t E, int D);
-int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* i, const int32_t* j, int64_t E, int D,
+int ceeg_edge_bce_fwd(const float* z, int64_t ldz, const int32_t* zidx, const int32_t* i, const int32_t* j, int64_t E, int D,
                       int negative, float* coef, float* prob, float* loss_sum,
                       void* ws, size_t ws_bytes, void* stream);
 

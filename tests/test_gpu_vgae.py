@@ -72,6 +72,8 @@ def test_edge_bce_and_recon_loss(D):
     _close(b.grad, a.grad)
     p = InnerProductDecoder()(b.detach(), ei.cuda())
     _close(p, ref_torch.decode(z0.double(), ei))
+    v = InnerProductDecoder()(b.detach(), ei.cuda(), sigmoid=False)   # the raw inner product, finite where the sigmoid saturates
+    _close(v, ref_torch.decode(z0.double(), ei, sigmoid=False))
 
 
 @pytest.mark.parametrize("N,E,D", [(3000, 50000, 128), (500, 20000, 32), (2000, 3000, 256), (700, 30000, 64), (900, 9000, 4),
@@ -181,6 +183,43 @@ def test_full_step_vs_oracle():
     loss, aux = model(x.cuda(), g, step=5, eps=eps.cuda(), sigma=sig)
     loss.backward()
     _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), {})
+
+
+def test_full_step_uniform_negatives_vs_oracle():
+    """The literal path of the north star: recon_loss over the positive edges and E pairs drawn by negative_sampling
+    (ceeg_neg_sample_uniform) every step.  The GPU's samples are bit-exact with the C oracle's Philox stream; loss and every
+    parameter gradient against the fp64 oracle fed the same explicit negatives; a second call with given negatives of
+    which some are (-1, -1) (samples the sampler gave up on) checks that such pairs are skipped and not counted."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph
+    from oracle import c_oracle, ref_torch
+    N, E, Fi, D, n_e = 3000, 48000, 32, 64, 128
+    ei_np = _graph(N, E, 7)
+    torch.manual_seed(0)
+    ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = VGAEVQ(Fi, D, n_e, 0.25, seed=3, negatives="uniform").cuda()
+    model.load_state_dict(ref.state_dict())
+    x, eps = torch.randn(N, Fi), torch.randn(N, D)
+    ei = torch.from_numpy(ei_np)
+    g = EventGraph(ei.cuda(), N)
+    loss, aux = model(x.cuda(), g, step=5, eps=eps.cuda())
+    loss.backward()
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, d = c_oracle.neg_sample_uniform(rowptr, col, N, E, model.negative_seed(5))
+    np.testing.assert_array_equal(aux["neg_edge_index"].cpu().numpy(), np.stack([s, d]))     # negative-sample indices bit-exact
+    assert (s >= 0).all() and int(aux["dec_sums"][2]) == E
+    neg_ei = torch.from_numpy(np.stack([s, d]).astype(np.int64))
+    _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, None), {})
+    # given negatives with holes
+    model.zero_grad(set_to_none=True)
+    s2, d2 = s.copy(), d.copy()
+    s2[::7] = -1; d2[::7] = -1
+    neg2 = torch.from_numpy(np.stack([s2, d2]))
+    loss2, aux2 = model(x.cuda(), g, step=5, eps=eps.cuda(), neg_edge_index=neg2.cuda())
+    loss2.backward()
+    assert int(aux2["dec_sums"][2]) == int((s2 >= 0).sum())
+    _check_step_against_fp64_oracle(ref, model, loss2, aux2, (x, ei, eps, neg2.to(torch.int64), torch.from_numpy(s2 >= 0)), {})
 
 
 @pytest.mark.parametrize("per_graph,D,n_e", [(True, 12, 32), (False, 12, 32), (True, 64, 100), (False, 64, 100)])
@@ -577,6 +616,34 @@ def test_fused_reparam_vq_backward_equals_the_two_steps(N, D, n_e, with_eps, mon
     assert got["cs"] is not None
     ref = ml.grad.double().sum(0)
     np.testing.assert_allclose(got["cs"].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()) + 1e-30)
+
+
+def test_head_bias_gradient_when_the_encoder_output_feeds_a_second_loss():
+    """aux['ml'] (the fused mu | logstd encoder output) also feeds the loss: autograd then ACCUMULATES a second gradient
+    into the tensor the fused reparam/VQ backward produced, and the column sums that kernel left for the head's bias
+    gradient no longer describe it.  The hint must be dropped (version check) and the bias gradients must still be exact."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
+    from oracle import ref_torch
+    N, E, Fi, D, n_e = 1500, 20000, 16, 16, 32
+    ei_np = _graph(N, E, 4)
+    torch.manual_seed(2)
+    ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = VGAEVQ(Fi, D, n_e, 0.25).cuda()
+    model.load_state_dict(ref.state_dict())
+    x, eps, r = torch.randn(N, Fi), torch.randn(N, D), torch.randn(N, 2 * D)
+    sig = sigma_params(N, 0, 1)
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    s, sg, valid = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1])
+    neg_ei = torch.from_numpy(np.stack([s, sg]).astype(np.int64))
+    ei = torch.from_numpy(ei_np)
+    loss, aux = model(x.cuda(), EventGraph(ei.cuda(), N), step=1, eps=eps.cuda(), sigma=sig)
+    (loss + (aux["ml"] * r.cuda()).sum()).backward()
+    ref = to64(ref)
+    loss_ref, aux_ref = ref(x.double(), ei, eps.double(), neg_ei, torch.from_numpy(valid), force_idx=aux["idx"].cpu())
+    (loss_ref + (torch.cat((aux_ref["mu"], aux_ref["logstd"]), dim=1) * r.double()).sum()).backward()
+    grads_close(model, ref)
 
 
 def test_decoder_code_form_with_condition_columns():
