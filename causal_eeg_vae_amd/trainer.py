@@ -6,16 +6,30 @@ import torch.distributed as dist
 
 
 def allreduce_grads_(params, world_size):
-    """Average gradients across ranks with ONE flat all-reduce (sum) followed by 1/world_size."""
+    """Average gradients across ranks with ONE flat all-reduce (sum) followed by 1/world_size.
+
+    Correct by construction for either backend:
+      * `nccl` (= RCCL): the collective is enqueued behind the backward's kernels (ProcessGroupNCCL makes its stream wait on
+        an event of the current stream, and `wait()` - implied by the synchronous call - makes the current stream wait for
+        the collective), `flat` stays referenced until after that wait, and the division and the copies back are ordinary
+        kernels on the current stream, i.e. ordered after it;
+      * any other backend (gloo: CPU tests, one-GPU rehearsals) never sees device memory: the current stream is
+        synchronised, the flat bucket crosses to the host with a blocking copy, is reduced there and copied back.
+        (Round 1: two ranks sharing one GPU dead-locked in the SECOND gloo all-reduce of a device tensor, both main threads
+        inside work.wait(); DESIGN.md section 6 has what the trace does and does not show.)"""
     grads = [p.grad for p in params if p.grad is not None]
     if not grads or world_size <= 1:
         return
+    if len(grads) != len(params):
+        # every rank must reduce the same bucket layout: a parameter without a gradient on one rank only would silently
+        # misalign (or hang) the exchange
+        raise RuntimeError("allreduce_grads_: some parameters have no gradient; the flat bucket would differ between ranks")
     flat = torch._utils._flatten_dense_tensors(grads)
-    if flat.is_cuda and dist.get_backend() == "gloo":
-        # rehearsal only (ranks sharing one GPU over gloo): gloo's device path dead-locks there, stage through the host
-        host = flat.cpu()
+    if flat.is_cuda and dist.get_backend() != "nccl":
+        torch.cuda.current_stream(flat.device).synchronize()
+        host = flat.to("cpu", non_blocking=False)
         dist.all_reduce(host, op=dist.ReduceOp.SUM)
-        flat.copy_(host)
+        flat.copy_(host, non_blocking=False)
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # RCCL: in place on the device, stream-ordered
     flat.div_(world_size)
