@@ -63,6 +63,10 @@ SIGNATURES = {
     "ceeg_gat_scores_fwd": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
     "ceeg_gat_scores_bwd_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int]),
     "ceeg_gat_scores_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _vp, _c_i64, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_graph_layernorm_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_i64]),
+    "ceeg_graph_layernorm_fwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_int, _c_i64, _vp, _vp, _c_f32, _c_int, _vp, _c_i64, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_graph_layernorm_bwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _vp, _c_i64,
+                                          _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
 }
 

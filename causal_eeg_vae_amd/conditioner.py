@@ -40,6 +40,6 @@ class GraphConditioner(nn.Module):
         # one attention CSR (self-loops replaced by one per node) for every layer
         pair = GATConv.attention_graph(input.edge_index, x.shape[0])
         seq = self.graph_sequential_model
-        for conv, norm, act in self._layers:
-            x = getattr(seq, act)(getattr(seq, norm)(getattr(seq, conv)(x.contiguous(), pair), batch, input.num_graphs))
+        for conv, norm, _act in self._layers:   # the ReLU module (kept for the state-dict numbering) runs inside the norm's kernel
+            x = getattr(seq, norm)(getattr(seq, conv)(x.contiguous(), pair), batch, input.num_graphs, relu=True)
         return self.pooling_layer(x, batch=batch, size=input.num_graphs)

@@ -1206,7 +1206,7 @@ int vq_forward_check(const void* z, const float* W, int64_t B, int n_e, int D, i
                      const float* loss, const float* perplexity) {
   if (!z || !W || !z_q || !idx || !loss || !perplexity || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
   if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
-  if (D > 256 || n_e > 16384 || B > ((int64_t)1 << 31) * 128) return CEEG_EUNSUPPORTED;
+  if (D > 256 || n_e > 4096 || B > ((int64_t)1 << 31) * 128) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(z, 16) || !ceeg_aligned(z_q, 16) || !ceeg_aligned(W, 16)) return CEEG_EINVAL;
   return CEEG_OK;
 }
@@ -1351,8 +1351,13 @@ extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* id
                                 void* ws, size_t ws_bytes, void* stream) {
   if (!z || !W || !idx || !s_dev || B <= 0 || n_e <= 0 || D <= 0) return CEEG_EINVAL;
   if (dtype != CEEG_F32 && dtype != CEEG_BF16) return CEEG_EUNSUPPORTED;
-  if (D > 256 || n_e > 16384 || B >= ((int64_t)1 << 32)) return CEEG_EUNSUPPORTED;
+  if (D > 256 || n_e > 4096 || B >= ((int64_t)1 << 32)) return CEEG_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  VqBwdWs w;
+  if (dW) {  // every argument is validated before the first launch
+    if (ws_bytes < vq_bwd_layout(B, n_e, D, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
+    if (!ws || !ceeg_aligned(ws, 256) || vq_bwd_layout(B, n_e, D, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  }
   if (dz) {
     const int64_t total = B * D;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
@@ -1366,9 +1371,6 @@ extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* id
     CEEG_CHECK_LAUNCH();
   }
   if (dW) {
-    VqBwdWs w;
-    if (ws_bytes < vq_bwd_layout(B, n_e, D, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
-    if (!ws || !ceeg_aligned(ws, 256) || vq_bwd_layout(B, n_e, D, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
     const int nslice = (int)vq_nslice(B);
     hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.hpart);
     CEEG_CHECK_LAUNCH();

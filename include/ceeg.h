@@ -66,7 +66,7 @@ int ceeg_check_device(void);
  *                  registers.  Environment CEEG_VQ_BF16_BS=0 forces the second one (a checker's switch).
  *
  * z [B,D], W [n_e,D] fp32, z_q [B,D] (dtype), idx [B] int64, loss/perplexity: 1 float each (device),
- * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 16384, B >= 1
+ * hist [n_e] uint32 (device, may be NULL).  Limits: 1 <= D <= 256, 1 <= n_e <= 4096 (the largest codebook the tests exercise), B >= 1
  * (B == 0 is CEEG_EINVAL: the reference divides by zero there).
  * ----------------------------------------------------------------------------------------------*/
 size_t ceeg_vq_forward_ws_bytes(int64_t B, int n_e, int D, int dtype);
@@ -333,6 +333,26 @@ int ceeg_segment_sum_perm(const int32_t* t_rowptr, const int32_t* t_perm, const 
 size_t ceeg_segment_sum_items_ws_bytes(int64_t n_items);
 int ceeg_segment_sum_perm_items(const int32_t* t_rowptr, const int32_t* t_perm, const float* v, int64_t N, const int32_t* items,
                                 int64_t n_items, int chunk, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * N4  torch_geometric.nn.LayerNorm(in_channels, mode='graph') as the reference instantiates it after every GATConv
+ * (scripts/models.py:107), optionally fused with the ReLU that follows it (scripts/models.py:108), over a collated batch:
+ * ptr int32 [G+1] = row offsets of the graphs (the batch is sorted by graph), rows [ptr[g], ptr[g+1]) belong to graph g.
+ *   mean_g, var_g over ALL rows and channels of graph g (biased variance; an empty graph counts as one row);
+ *   out = (x - mean_g) / sqrt(var_g + eps) * weight + bias  [then max(., 0) when relu != 0]
+ * Forward: two reads of x and one write; the statistics are fp64 sums in a fixed order (no atomics).  mean / rstd ([G]
+ * DOUBLES: x - mean keeps the digits a rounded mean would lose when |mean| >> std) are outputs the backward takes back.  weight / bias may be NULL (affine=False).
+ * Backward (y = the forward's output, needed only with relu != 0 for the mask): with gm = g * [y > 0], xhat = (x-mean) rstd,
+ *   dx = rstd * (gm w - mean_g(gm w) - xhat mean_g(gm w xhat)),  dweight[f] = sum_n gm xhat,  dbias[f] = sum_n gm
+ * (dweight / dbias may be NULL).  F % 4 == 0, F <= 2048, row strides multiples of 4, 16-byte aligned pointers. */
+size_t ceeg_graph_layernorm_ws_bytes(int64_t N, int F, int64_t G);
+int ceeg_graph_layernorm_fwd(const float* x, int64_t ldx, const int32_t* ptr, int64_t N, int F, int64_t G, const float* weight,
+                             const float* bias, float eps, int relu, float* out, int64_t ldo, double* mean, double* rstd,
+                             void* ws, size_t ws_bytes, void* stream);
+int ceeg_graph_layernorm_bwd(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* y, int64_t ldy,
+                             const int32_t* ptr, int64_t N, int F, int64_t G, const float* weight, const double* mean,
+                             const double* rstd, int relu, float* dx, int64_t lddx, float* dweight, float* dbias,
+                             void* ws, size_t ws_bytes, void* stream);
 
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected

@@ -426,6 +426,48 @@ def test_global_attention_and_graph_layernorm_vs_oracle():
         _close(b2.grad, a2.grad)
 
 
+@pytest.mark.parametrize("F,relu,affine,offset", [(2048, True, True, 0.0), (64, False, True, 0.0), (12, True, False, 0.0), (256, True, True, 300.0)])
+def test_graph_layernorm_kernels(F, relu, affine, offset):
+    """ceeg_graph_layernorm_fwd / _bwd (scripts/models.py:107-108: LayerNorm(mode='graph') + ReLU) vs the
+    fp64 restatement: output, input gradient, weight / bias gradients; graphs of 1 .. 5000 nodes and an EMPTY graph in the
+    middle; a batch whose mean is 300 standard deviations away from zero (fp64 statistics); bitwise reproducible."""
+    from causal_eeg_vae_amd.pool import GraphLayerNorm
+    from oracle import ref_torch
+    sizes = [1, 5000, 3, 0, 70, 64, 65, 900]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, G = int(batch.shape[0]), len(sizes)
+    torch.manual_seed(F)
+    x = torch.randn(N, F) + offset
+    r = torch.randn(N, F)
+    ln = GraphLayerNorm(F, affine=affine).cuda()
+    w64 = b64 = None
+    if affine:
+        with torch.no_grad():
+            ln.weight.normal_(); ln.bias.normal_()
+        w64 = ln.weight.detach().cpu().double().requires_grad_(True)
+        b64 = ln.bias.detach().cpu().double().requires_grad_(True)
+    a = x.double().requires_grad_(True)
+    ref = ref_torch.ref_graph_layer_norm(a, batch, G, w64, b64)
+    if relu:
+        ref = ref.relu()
+    (ref * r.double()).sum().backward()
+    outs = []
+    for _ in range(2):
+        ln.zero_grad(set_to_none=True)
+        b = x.clone().cuda().requires_grad_(True)
+        out = ln(b, batch.cuda(), G, relu=relu)
+        (out * r.cuda()).sum().backward()
+        outs.append((out.detach(), b.grad, None if not affine else ln.weight.grad.clone(), None if not affine else ln.bias.grad.clone()))
+    for u, v in zip(outs[0], outs[1]):
+        assert u is None or torch.equal(u, v)
+    out, dx, dw, db = outs[0]
+    _close(out, ref)
+    _close(dx, a.grad)
+    if affine:
+        _close(dw, w64.grad)
+        _close(db, b64.grad)
+
+
 @pytest.mark.parametrize("D", [128, 32])
 def test_fused_decoder_indegree_hubs(D):
     """Destination hubs (rows of 700, 300 and 5000 entries: split at global 256-entry positions and computed piecewise)

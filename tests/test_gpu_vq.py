@@ -180,6 +180,39 @@ def test_large_properties_and_determinism():
         np.testing.assert_allclose(g1.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
 
 
+def test_largest_codebook_forward_backward_and_argument_checks():
+    """n_e = 4096 (the advertised limit): forward bit-exact vs the C oracle, both gradients vs the closed forms in fp64; one
+    more code is refused; a bad dW workspace is refused BEFORE anything is launched (dz stays untouched)."""
+    from causal_eeg_vae_amd import _lib
+    from oracle import c_oracle
+    B, n_e, D = 700, 4096, 32
+    rng = np.random.default_rng(1)
+    W = rng.standard_normal((n_e, D)).astype(np.float32)
+    zn = rng.standard_normal((B, D)).astype(np.float32)
+    vq = _mod(n_e, D, 0.25, W, one_hot=False)
+    z = torch.from_numpy(zn).cuda().requires_grad_(True)
+    loss, z_q, ppl, _, idx = vq(z)
+    o = c_oracle.vq_forward_f32(zn, W, 0.25)
+    np.testing.assert_array_equal(idx[:, 0].cpu().numpy(), o["idx"])
+    np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-5)
+    r = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    (loss + (z_q * r).sum()).backward()
+    z64, W64, i64 = torch.from_numpy(zn).double(), torch.from_numpy(W).double(), torch.from_numpy(o["idx"])
+    dz = r.cpu().double() + 2.0 / (B * D) * (z64 - W64[i64])
+    dW = torch.zeros_like(W64).index_add_(0, i64, W64[i64] - z64) * (0.25 * 2.0 / (B * D))
+    np.testing.assert_allclose(z.grad.cpu().double().numpy(), dz.numpy(), rtol=1e-5, atol=1e-6 * float(dz.abs().max()))
+    np.testing.assert_allclose(vq.embedding.weight.grad.cpu().double().numpy(), dW.numpy(), rtol=1e-5, atol=1e-6 * float(dW.abs().max()))
+    L = _lib.lib()
+    p = z.data_ptr()
+    assert L.ceeg_vq_forward(p, p, B, 4097, D, 0, 0.25, p, p, p, p, None, p, 1 << 30, _lib.stream()) == -2   # unsupported: no launch
+    dzb = torch.full((B, D), 7.0, device="cuda")
+    s = torch.ones(1, device="cuda")
+    rc = L.ceeg_vq_backward(z.data_ptr(), vq.embedding.weight.data_ptr(), idx.data_ptr(), None, s.data_ptr(), B, n_e, D, 0, 0.25,
+                            dzb.data_ptr(), vq.embedding.weight.grad.data_ptr(), None, 0, _lib.stream())
+    torch.cuda.synchronize()
+    assert rc == -3 and bool((dzb == 7.0).all())
+
+
 def test_errors_are_loud():
     from causal_eeg_vae_amd import VectorQuantizer, CeegError
     vq = VectorQuantizer(16, 8, 0.25)
