@@ -67,6 +67,8 @@ SIGNATURES = {
     "ceeg_graph_layernorm_fwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _c_int, _c_i64, _vp, _vp, _c_f32, _c_int, _vp, _c_i64, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_graph_layernorm_bwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_int, _c_i64, _vp, _vp, _vp, _c_int, _vp, _c_i64,
                                           _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_segment_ids": (_c_int, [_vp, _c_i64, _c_i64, _vp, _vp]),
+    "ceeg_collate_edges": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _c_i64, _vp, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
 }
 

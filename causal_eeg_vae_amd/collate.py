@@ -1,0 +1,80 @@
+"""PyG-style collation of disjoint graphs on the device.
+
+The reference batches its samples with `torch_geometric.loader.DataLoader(dataset, batch_size, follow_batch=[...])`
+(scripts/run.py:310-326): node-level tensors concatenated, `edge_index` offset block-diagonally by the cumulative node
+counts, a `batch` vector with the graph id of every node, one `<key>_batch` vector per followed key, and reads single samples
+back out of the collated storage with `torch_geometric.data.separate` (scripts/dataset.py:66-92).  Here the per-element work
+(offsetting, graph ids) is two HIP kernels over the already concatenated tensors (ceeg_collate_edges, ceeg_segment_ids);
+only the list of per-graph sizes is host data, as it is in PyG's `slice_dict`.
+"""
+import torch
+
+from . import _lib
+
+
+def _ptr(counts, device):
+    p = torch.zeros(len(counts) + 1, dtype=torch.int64)
+    if len(counts):
+        p[1:] = torch.as_tensor(list(counts), dtype=torch.int64).cumsum(0)
+    return p.to(device)
+
+
+def segment_ids(ptr, total):
+    """[total] int64: the segment (graph) of every element, from ascending offsets ptr [G+1]."""
+    out = torch.empty(max(int(total), 1), dtype=torch.int64, device=ptr.device)[: int(total)]
+    _lib.check(_lib.lib().ceeg_segment_ids(ptr.data_ptr(), ptr.shape[0] - 1, int(total), out.data_ptr(), _lib.stream()), "ceeg_segment_ids")
+    return out
+
+
+class CollatedBatch:
+    """The collated form of a list of graphs: `edge_index` [2, sum E] (offset), `batch` [sum N], `ptr` / `edge_ptr` [G+1]
+    (PyG's slice_dict for nodes and edges), `num_nodes`, `num_graphs`, and per followed key `<key>` (concatenated rows),
+    `<key>_batch` and `<key>_ptr`."""
+
+    def __init__(self, edge_indices, nodes_per_graph, follow=None):
+        if len(edge_indices) != len(nodes_per_graph) or not len(edge_indices):
+            raise ValueError("one edge_index and one node count per graph")
+        dev = edge_indices[0].device
+        _lib.require_cuda(*edge_indices)
+        self.num_graphs = G = len(edge_indices)
+        self.ptr = _ptr(nodes_per_graph, dev)
+        self.edge_ptr = _ptr([int(e.shape[1]) for e in edge_indices], dev)
+        self.num_nodes = int(sum(int(n) for n in nodes_per_graph))
+        raw = torch.cat([e.to(torch.int64) for e in edge_indices], dim=1).contiguous()   # one concatenation, no per-graph arithmetic
+        E = raw.shape[1]
+        self.edge_index = torch.empty_like(raw)
+        self.edge_batch = torch.empty(max(E, 1), dtype=torch.int64, device=dev)[:E]
+        _lib.check(_lib.lib().ceeg_collate_edges(raw.data_ptr(), raw.stride(0), self.edge_ptr.data_ptr(), self.ptr.data_ptr(), G, E, 1,
+                                                 self.edge_index.data_ptr(), self.edge_index.stride(0), self.edge_batch.data_ptr(), _lib.stream()),
+                   "ceeg_collate_edges")
+        self.batch = segment_ids(self.ptr, self.num_nodes)
+        self.followed = {}
+        for key, parts in (follow or {}).items():          # follow_batch=[key, ...]: rows of `key` belong to their sample's graph
+            if len(parts) != G:
+                raise ValueError(f"followed key {key!r}: one tensor per graph")
+            kp = _ptr([int(t.shape[0]) for t in parts], dev)
+            val = torch.cat(list(parts), dim=0)
+            self.followed[key] = (val, segment_ids(kp, val.shape[0]), kp)
+            setattr(self, key, val)
+            setattr(self, key + "_batch", self.followed[key][1])
+            setattr(self, key + "_ptr", kp)
+
+    def separate(self, idx):
+        """The idx-th graph back out of the collated storage (torch_geometric.data.separate): its edge_index with the node
+        offset subtracted again, its node count, and its slice of every followed key."""
+        i = int(idx)
+        if not 0 <= i < self.num_graphs:
+            raise IndexError(i)
+        lo, hi = int(self.edge_ptr[i]), int(self.edge_ptr[i + 1])     # slice_dict lookups: host values, as in PyG
+        n_lo, n_hi = int(self.ptr[i]), int(self.ptr[i + 1])
+        sl = self.edge_index[:, lo:hi]
+        out = torch.empty(2, hi - lo, dtype=torch.int64, device=sl.device)
+        if hi > lo:
+            one_e = torch.tensor([0, hi - lo], dtype=torch.int64, device=sl.device)
+            one_n = torch.tensor([n_lo, n_hi], dtype=torch.int64, device=sl.device)
+            _lib.check(_lib.lib().ceeg_collate_edges(sl.data_ptr(), sl.stride(0), one_e.data_ptr(), one_n.data_ptr(), 1, hi - lo, -1,
+                                                     out.data_ptr(), out.stride(0), None, _lib.stream()), "ceeg_collate_edges")
+        parts = {}
+        for key, (val, _, kp) in self.followed.items():
+            parts[key] = val[int(kp[i]): int(kp[i + 1])]
+        return out, n_hi - n_lo, parts

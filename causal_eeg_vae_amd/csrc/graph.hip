@@ -272,3 +272,55 @@ extern "C" int ceeg_neg_sample_uniform(const int32_t* rowptr, const int32_t* col
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- collation (N2)
+// PyG-style batching of disjoint graphs (torch_geometric DataLoader / Batch.from_data_list as the reference calls it at
+// scripts/run.py:310-326 with follow_batch=[...], and its inverse `separate`, scripts/dataset.py:66-92), on the device:
+//   ceeg_segment_ids   : out[i] = g for ptr[g] <= i < ptr[g+1]  - the `batch` vector and every followed key's `<key>_batch`
+//   ceeg_collate_edges : dst_edges[:, e] = src_edges[:, e] + sign * node_ptr[g(e)], g(e) from edge_ptr - block-diagonal
+//                        offsetting (sign = +1) and its inverse (sign = -1: what `separate` subtracts again)
+// Streaming integer work; the graph of an element is a binary search in the (L2-resident) ptr array.
+namespace {
+__device__ __forceinline__ int seg_of(const int64_t* __restrict__ ptr, int G, int64_t i) {
+  int lo = 0, hi = G;  // last g with ptr[g] <= i (empty graphs have ptr[g] == ptr[g+1] and are skipped)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+__global__ void segment_ids_kernel(const int64_t* __restrict__ ptr, int G, int64_t total, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) out[i] = seg_of(ptr, G, i);
+}
+__global__ void collate_edges_kernel(const int64_t* __restrict__ in, int64_t ld_in, const int64_t* __restrict__ edge_ptr,
+                                     const int64_t* __restrict__ node_ptr, int G, int64_t E, int sign, int64_t* __restrict__ out,
+                                     int64_t ld_out, int64_t* __restrict__ edge_batch) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int g = seg_of(edge_ptr, G, e);
+  const int64_t off = sign * node_ptr[g];
+  out[e] = in[e] + off;
+  out[ld_out + e] = in[ld_in + e] + off;
+  if (edge_batch) edge_batch[e] = g;
+}
+}  // namespace
+
+extern "C" int ceeg_segment_ids(const int64_t* ptr, int64_t G, int64_t total, int64_t* out, void* stream) {
+  if (!ptr || G <= 0 || total < 0 || G >= ((int64_t)1 << 31) || (total > 0 && !out)) return CEEG_EINVAL;
+  if (total == 0) return CEEG_OK;
+  hipLaunchKernelGGL(segment_ids_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), ptr, (int)G, total, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_collate_edges(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
+                                  int64_t E, int sign, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, void* stream) {
+  if (!edge_ptr || !node_ptr || G <= 0 || E < 0 || G >= ((int64_t)1 << 31) || (sign != 1 && sign != -1)) return CEEG_EINVAL;
+  if (E == 0) return CEEG_OK;
+  if (!edges_in || !edges_out || ld_in < E || ld_out < E) return CEEG_EINVAL;
+  hipLaunchKernelGGL(collate_edges_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), edges_in, ld_in,
+                     edge_ptr, node_ptr, (int)G, E, sign, edges_out, ld_out, edge_batch);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}

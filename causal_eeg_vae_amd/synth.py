@@ -46,7 +46,13 @@ def synth_features(num_nodes, dim, seed=0, device="cpu"):
 
 
 def collate_graphs(edge_indices, nodes_per_graph):
-    """PyG-style block-diagonal collation (scripts/run.py:310): offsets added to edge_index, `batch` vector."""
+    """PyG-style block-diagonal collation (scripts/run.py:310): offsets added to edge_index, `batch` vector.
+    On the GPU this is causal_eeg_vae_amd.collate.CollatedBatch (two HIP kernels over the concatenated lists); CPU inputs
+    (the oracle side of the tests) take the plain torch restatement below."""
+    if edge_indices and edge_indices[0].is_cuda:
+        from .collate import CollatedBatch
+        c = CollatedBatch(edge_indices, nodes_per_graph)
+        return c.edge_index, c.batch, c.num_nodes
     offs, eis, batch = 0, [], []
     for g, (ei, n) in enumerate(zip(edge_indices, nodes_per_graph)):
         eis.append(ei + offs)

@@ -354,6 +354,20 @@ int ceeg_graph_layernorm_bwd(const float* g, int64_t ldg, const float* x, int64_
                              const double* rstd, int relu, float* dx, int64_t lddx, float* dweight, float* dbias,
                              void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N2  PyG-style collation of disjoint graphs on the device - torch_geometric.loader.DataLoader(..., follow_batch=[...]) as
+ * the reference calls it (scripts/run.py:310-326) and its inverse torch_geometric.data.separate (scripts/dataset.py:66-92).
+ *   ceeg_segment_ids  : out[i] = g for ptr[g] <= i < ptr[g+1], i in [0, total) - the `batch` vector (ptr = node offsets)
+ *                       and every followed key's `<key>_batch` vector (ptr = that key's row offsets).  ptr: int64 [G+1],
+ *                       ascending, ptr[0] = 0, ptr[G] = total; empty segments allowed.
+ *   ceeg_collate_edges: edges_out[r*ld_out + e] = edges_in[r*ld_in + e] + sign * node_ptr[g(e)] for r = 0, 1, where g(e) is
+ *                       the graph of edge e by edge_ptr (int64 [G+1]); sign = +1 is the block-diagonal offsetting of the
+ *                       concatenated per-graph edge lists, sign = -1 its inverse (what `separate` returns for a slice).
+ *                       edge_batch (int64 [E] or NULL) receives g(e).  In place (edges_out == edges_in) is allowed. */
+int ceeg_segment_ids(const int64_t* ptr, int64_t G, int64_t total, int64_t* out, void* stream);
+int ceeg_collate_edges(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
+                       int64_t E, int sign, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, void* stream);
+
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
  * when src==dst or src->dst is an edge of the given CSR (rows=dst, src-sorted), up to 16 attempts; a

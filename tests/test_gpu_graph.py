@@ -254,3 +254,42 @@ def test_gat_entry_points_reject_bad_arguments():
     assert L.ceeg_segment_sum_perm_items(rp.data_ptr(), None, v.data_ptr(), N, None, 0, 256, out.data_ptr(), None, 0, st) == 0
     torch.cuda.synchronize()
     assert float(out.abs().max()) == 0.0
+
+
+def test_device_collation_follow_batch_and_separate_round_trip():
+    """CollatedBatch (ceeg_collate_edges + ceeg_segment_ids) against a per-graph restatement of
+    what PyG's DataLoader(..., follow_batch=[...]) builds (scripts/run.py:310-326) - offset edge_index, `batch`, `ptr`, one
+    `<key>_batch` per followed key - and `separate` (scripts/dataset.py:66-92) returning every sample bit for bit; graphs
+    without edges, without nodes, and a followed key with zero rows in some samples."""
+    from causal_eeg_vae_amd import CollatedBatch
+    rng = np.random.default_rng(0)
+    sizes = [5, 1, 0, 300, 17, 2000, 1]
+    n_edges = [9, 0, 0, 4000, 40, 30000, 0]
+    tok_rows = [5, 1, 0, 7, 0, 33, 2]            # a followed key with its own row count per sample (e.g. token rows)
+    eis, toks = [], []
+    for n, e, t in zip(sizes, n_edges, tok_rows):
+        eis.append(torch.from_numpy(rng.integers(0, max(n, 1), (2, e))).to(torch.int64))
+        toks.append(torch.from_numpy(rng.standard_normal((t, 6)).astype(np.float32)))
+    c = CollatedBatch([e.cuda() for e in eis], sizes, follow={"input_ids": [t.cuda() for t in toks]})
+    # the restatement: one graph at a time
+    offs, want_ei, want_batch, want_tb = 0, [], [], []
+    for g, (ei, n, t) in enumerate(zip(eis, sizes, toks)):
+        want_ei.append(ei + offs)
+        want_batch.append(torch.full((n,), g, dtype=torch.int64))
+        want_tb.append(torch.full((t.shape[0],), g, dtype=torch.int64))
+        offs += n
+    assert c.num_nodes == offs and c.num_graphs == len(sizes)
+    assert torch.equal(c.edge_index.cpu(), torch.cat(want_ei, dim=1))
+    assert torch.equal(c.batch.cpu(), torch.cat(want_batch))
+    assert torch.equal(c.edge_batch.cpu(), torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(n_edges)))
+    assert c.ptr.cpu().tolist() == np.concatenate([[0], np.cumsum(sizes)]).tolist()
+    assert torch.equal(c.input_ids.cpu(), torch.cat(toks)) and torch.equal(c.input_ids_batch.cpu(), torch.cat(want_tb))
+    for g in range(len(sizes)):
+        ei, n, parts = c.separate(g)
+        assert n == sizes[g] and torch.equal(ei.cpu(), eis[g]) and torch.equal(parts["input_ids"].cpu(), toks[g])
+    # the function the models use returns the same tensors
+    from causal_eeg_vae_amd.synth import collate_graphs
+    e2, b2, n2 = collate_graphs([e.cuda() for e in eis], sizes)
+    assert n2 == offs and torch.equal(e2, c.edge_index) and torch.equal(b2, c.batch)
+    L = __import__("causal_eeg_vae_amd")._lib.lib()
+    assert L.ceeg_collate_edges(None, 0, c.ptr.data_ptr(), c.ptr.data_ptr(), 0, 5, 1, None, 0, None, None) < 0   # G = 0: refused
