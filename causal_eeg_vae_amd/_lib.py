@@ -69,6 +69,11 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_segment_ids": (_c_int, [_vp, _c_i64, _c_i64, _vp, _vp]),
     "ceeg_collate_edges": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _c_i64, _vp, _vp]),
+    "ceeg_top_predecessors": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _vp, _vp]),
+    "ceeg_ancestors_cap": (_c_int, [_c_int, _c_int]),
+    "ceeg_ancestors": (_c_int, [_vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
+    "ceeg_ancestor_subgraph_count": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp]),
+    "ceeg_ancestor_subgraph_fill": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp, _vp, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
 }
 

@@ -88,3 +88,63 @@ def ancestor_subgraph(edge_index, entities, num_nodes, node, index=None):
     m = np.isin(ei[0], keep) & np.isin(ei[1], keep)
     sub = np.array([[loc[int(a)] for a in ei[0][m]], [loc[int(b)] for b in ei[1][m]]], dtype=np.int64).reshape(2, -1)
     return sub, keep
+
+
+class DeviceAncestors:
+    """The ancestor extraction for EVERY target node at once on the GPU (ceeg_top_predecessors / ceeg_ancestors /
+    ceeg_ancestor_subgraph_*): what `PredecessorIndex.ancestors` and `ancestor_subgraph` compute one node at a time.
+
+        da = DeviceAncestors(edge_index, entities, num_nodes)            # device tensors; edges in first-appearance order
+        da.anc [T, cap] int32 (sorted, -1 padded), da.count [T]
+        sub_edge_index, edge_ptr = da.subgraphs()                        # local ids, edges of target t at [edge_ptr[t], edge_ptr[t+1])
+    """
+
+    def __init__(self, edge_index, entities, num_nodes, targets=None, num_gens=NUM_GENERATIONS, num_predecessors=MAX_TOP_PREDECESSORS,
+                 min_entities=MIN_COMMON_ENTITIES):
+        import torch
+        from . import _lib
+        from .models import CsrPair
+        _lib.require_cuda(edge_index, entities)
+        L = _lib.lib()
+        dev = edge_index.device
+        N, n = int(num_nodes), int(num_predecessors)
+        self.pair = CsrPair(edge_index, N, self_loops=False)
+        ent = entities.to(torch.int64).contiguous()
+        if ent.numel() == 0:
+            ent = torch.zeros(1, dtype=torch.int64, device=dev)
+        col = self.pair.col if self.pair.nnz else torch.zeros(1, dtype=torch.int32, device=dev)
+        perm = self.pair.perm if self.pair.nnz else torch.zeros(1, dtype=torch.int32, device=dev)
+        self._col = col
+        self.top = torch.empty(N, n, dtype=torch.int32, device=dev)
+        _lib.check(L.ceeg_top_predecessors(self.pair.rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), ent.data_ptr(), N, n, int(min_entities),
+                                           self.top.data_ptr(), _lib.stream()), "ceeg_top_predecessors")
+        cap = int(L.ceeg_ancestors_cap(n, int(num_gens)))
+        if cap < 0:
+            raise ValueError("num_predecessors + ... + num_predecessors^num_gens exceeds what the kernel holds (128)")
+        self.cap = max(cap, 1)
+        tg = None if targets is None else targets.to(torch.int32).contiguous()
+        self.T = N if tg is None else int(tg.shape[0])
+        self.anc = torch.empty(self.T, self.cap, dtype=torch.int32, device=dev)
+        self.count = torch.empty(self.T, dtype=torch.int32, device=dev)
+        _lib.check(L.ceeg_ancestors(self.top.data_ptr(), N, n, _lib.ptr(tg), self.T, int(num_gens), self.cap, self.anc.data_ptr(),
+                                    self.count.data_ptr(), _lib.stream()), "ceeg_ancestors")
+
+    def subgraphs(self):
+        """(sub_edge_index [2, total] int32 with LOCAL ids, edge_ptr [T+1] int64): the induced subgraph of every target's
+        ancestors, edges ordered by (target slot, source id) inside each subgraph."""
+        import torch
+        from . import _lib
+        L = _lib.lib()
+        dev = self.anc.device
+        slots = torch.empty(self.T * self.cap, dtype=torch.int64, device=dev)
+        args = (self.pair.rowptr.data_ptr(), self._col.data_ptr(), self.anc.data_ptr(), self.count.data_ptr(), self.T, self.cap)
+        _lib.check(L.ceeg_ancestor_subgraph_count(*args, slots.data_ptr(), _lib.stream()), "ceeg_ancestor_subgraph_count")
+        incl = slots.cumsum(0)
+        off = (incl - slots).contiguous()
+        total = int(incl[-1].item()) if slots.numel() else 0         # dataset-construction time: one host sync
+        sub = torch.empty(2, max(total, 1), dtype=torch.int32, device=dev)[:, :total]
+        if total:
+            _lib.check(L.ceeg_ancestor_subgraph_fill(*args, off.data_ptr(), sub[0].data_ptr(), sub[1].data_ptr(), _lib.stream()),
+                       "ceeg_ancestor_subgraph_fill")
+        edge_ptr = torch.cat([off.view(self.T, self.cap)[:, 0], incl[-1:]]) if slots.numel() else torch.zeros(1, dtype=torch.int64, device=dev)
+        return sub, edge_ptr

@@ -368,6 +368,30 @@ int ceeg_segment_ids(const int64_t* ptr, int64_t G, int64_t total, int64_t* out,
 int ceeg_collate_edges(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
                        int64_t E, int sign, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * N3  Ancestor-subgraph extraction of the reference's dataset builder for ALL targets at once (scripts/dataset.py:22-46,
+ * 201-225), a frontier expansion on the device.  The graph comes as the CSR grouped by target of ceeg_csr_build
+ * (self_loops = 0: rowptr / col / perm, perm = edge id) plus `entities` [E] int64 by edge id (how many CSV rows collapsed
+ * into the edge, dataset.py:147-153; edges numbered in first-appearance order).
+ *   ceeg_top_predecessors: top[v*n + i] = i-th of v's predecessors with entities >= min_entities, heaviest first, ties by edge
+ *       id ascending, at most min(n, in-degree of v) of them, -1 padded (get_top_n_valid_predecessors, dataset.py:22-33).
+ *   ceeg_ancestors: anc[t*cap + .] = sorted, duplicate-free union of the top predecessors over `gens` generations from
+ *       targets[t] (NULL: t itself), -1 padded; cnt[t] = how many (get_n_gen_ancestors, dataset.py:35-46).
+ *       cap >= ceeg_ancestors_cap(n, gens) = n + n^2 + ... + n^gens (39 for the reference's 3 and 3), <= 128.
+ *   ceeg_ancestor_subgraph_count / _fill: the edges induced on each target's ancestors (dataset.py:201-225) with LOCAL ids
+ *       (position in the sorted list).  count writes slot_count[t*cap + k] = edges INTO the k-th ancestor; the caller takes the
+ *       exclusive prefix sum (slot_off) and fill writes the (source, target) pairs of target t's subgraph at
+ *       [slot_off[t*cap], slot_off[(t+1)*cap]) ordered by (target slot, source id): a collated batch of subgraphs. */
+int ceeg_top_predecessors(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int64_t* entities, int64_t N,
+                          int n, int64_t min_entities, int32_t* top, void* stream);
+int ceeg_ancestors_cap(int n, int gens);
+int ceeg_ancestors(const int32_t* top, int64_t N, int n, const int32_t* targets, int64_t T, int gens, int cap, int32_t* anc,
+                   int32_t* cnt, void* stream);
+int ceeg_ancestor_subgraph_count(const int32_t* rowptr, const int32_t* col, const int32_t* anc, const int32_t* cnt, int64_t T, int cap,
+                                 int64_t* slot_count, void* stream);
+int ceeg_ancestor_subgraph_fill(const int32_t* rowptr, const int32_t* col, const int32_t* anc, const int32_t* cnt, int64_t T, int cap,
+                                const int64_t* slot_off, int32_t* sub_src, int32_t* sub_dst, void* stream);
+
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
  * when src==dst or src->dst is an edge of the given CSR (rows=dst, src-sorted), up to 16 attempts; a

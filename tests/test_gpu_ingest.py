@@ -1,0 +1,60 @@
+"""GPU: ancestor extraction for all targets at once (ceeg_top_predecessors / ceeg_ancestors /
+ceeg_ancestor_subgraph_*) against the host path of causal_eeg_vae_amd/ingest.py, which tests/test_ingest_cpu.py checks
+against a pandas + networkx restatement of scripts/dataset.py:22-46,122-156,201-225.  Synthetic tables of the reference's CSV
+schema (parity unpinned: the reference holds no expected output for this step)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+pd = pytest.importorskip("pandas")
+
+from test_ingest_cpu import _tables  # noqa: E402
+
+
+@pytest.mark.parametrize("n_nodes,n_rows,seed", [(97, 234, 0), (400, 3000, 1), (30, 10, 2), (3000, 40000, 3)])
+def test_device_ancestors_equal_host_extraction(tmp_path, n_nodes, n_rows, seed):
+    from causal_eeg_vae_amd import ingest
+    ncsv, ecsv = _tables(tmp_path, n_nodes, n_rows, seed)
+    g = ingest.load_event_graph_csv(ncsv, ecsv)
+    N = g["num_nodes"]
+    ei, ent = g["edge_index"], g["entities"]
+    host = ingest.PredecessorIndex(ei, ent, N)
+    da = ingest.DeviceAncestors(torch.from_numpy(ei).cuda(), torch.from_numpy(ent).cuda(), N)
+    top = da.top.cpu().numpy()
+    anc, cnt = da.anc.cpu().numpy(), da.count.cpu().numpy()
+    sub, eptr = da.subgraphs()
+    sub, eptr = sub.cpu().numpy(), eptr.cpu().numpy()
+    assert eptr[0] == 0 and eptr[-1] == sub.shape[1] and (np.diff(eptr) >= 0).all()
+    n_anc = 0
+    for v in range(N):
+        want_top = host.top_predecessors(v, ingest.MAX_TOP_PREDECESSORS)
+        assert [int(x) for x in top[v] if x >= 0] == want_top               # order matters: heaviest first, ties by first appearance
+        want = sorted(host.ancestors(v))
+        assert cnt[v] == len(want) and anc[v, : cnt[v]].tolist() == want and (anc[v, cnt[v]:] == -1).all()
+        n_anc += len(want)
+        hsub, keep = ingest.ancestor_subgraph(ei, ent, N, v, host)
+        assert keep == want
+        mine = sub[:, eptr[v]: eptr[v + 1]]
+        key = lambda a: sorted(zip(a[1].tolist(), a[0].tolist()))             # canonical (target, source) order
+        assert key(mine) == key(hsub)
+        assert mine.shape[1] == 0 or list(zip(mine[1].tolist(), mine[0].tolist())) == key(mine)   # already emitted in that order
+    if n_rows > 100:
+        assert n_anc > 0
+    # a subset of targets, fewer generations / predecessors
+    tg = torch.arange(0, N, 3, dtype=torch.int64).cuda()
+    d2 = ingest.DeviceAncestors(torch.from_numpy(ei).cuda(), torch.from_numpy(ent).cuda(), N, targets=tg, num_gens=2, num_predecessors=2)
+    a2, c2 = d2.anc.cpu().numpy(), d2.count.cpu().numpy()
+    for i, v in enumerate(tg.cpu().tolist()):
+        assert a2[i, : c2[i]].tolist() == sorted(host.ancestors(v, 2, 2))
+
+
+def test_device_ancestors_argument_checks():
+    from causal_eeg_vae_amd import _lib
+    L = _lib.lib()
+    assert L.ceeg_ancestors_cap(3, 3) == 39 and L.ceeg_ancestors_cap(2, 2) == 6 and L.ceeg_ancestors_cap(8, 3) == -1
+    t = torch.zeros(64, dtype=torch.int32, device="cuda")
+    p = t.data_ptr()
+    assert L.ceeg_top_predecessors(p, p, p, p, 4, 9, 3, p, _lib.stream()) == -2          # more predecessors than the kernel keeps
+    assert L.ceeg_ancestors(p, 4, 3, None, 4, 3, 10, p, p, _lib.stream()) == -2          # cap below 39
+    assert L.ceeg_ancestors(None, 4, 3, None, 4, 3, 39, p, p, _lib.stream()) == -1
