@@ -74,6 +74,8 @@ SIGNATURES = {
     "ceeg_ancestors": (_c_int, [_vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),
     "ceeg_ancestor_subgraph_count": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp]),
     "ceeg_ancestor_subgraph_fill": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp, _vp, _vp]),
+    "ceeg_token_pool_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp]),
+    "ceeg_token_pool_bwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
 }
 

@@ -7,7 +7,7 @@ import torch
 import torch.nn as nn
 
 from .models import GATConv
-from .pool import GlobalAttention, GraphLayerNorm
+from .pool import GlobalAttention, GraphLayerNorm, token_attention_pool
 
 
 class GraphConditioner(nn.Module):
@@ -34,8 +34,8 @@ class GraphConditioner(nn.Module):
     def forward(self, input):
         output = self.embedding(input_ids=input.input_ids, attention_mask=input.attention_mask)
         hidden = output.last_hidden_state                                        # [N, T, H]
-        attn_weights = self.attn(hidden)                                         # [N, T, 1]   (scripts/models.py:118)
-        x = torch.bmm(hidden.permute(0, 2, 1), attn_weights).squeeze(2)          # [N, H]      (scripts/models.py:119)
+        # attn_weights = self.attn(hidden); x = bmm(hidden^T, attn_weights).squeeze(2)   (scripts/models.py:118-119), one kernel
+        x = token_attention_pool(hidden, self.attn)                              # [N, H]
         batch = input.input_ids_batch
         # one attention CSR (self-loops replaced by one per node) for every layer
         pair = GATConv.attention_graph(input.edge_index, x.shape[0])

@@ -132,3 +132,47 @@ class GraphLayerNorm(nn.Module):
     def forward(self, x, batch, size=None, relu=False):
         ptr = graph_ptr(batch, size)
         return _GraphLayerNormFn.apply(x, ptr, self.weight, self.bias, self.eps, bool(relu))
+
+
+class _TokenPool(torch.autograd.Function):
+    """x[n] = sum_t (<hidden[n,t], w> + b) hidden[n,t]  (ceeg_token_pool_fwd / _bwd): the reference's
+    `torch.bmm(hidden.permute(0, 2, 1), self.attn(hidden)).squeeze(2)` (scripts/models.py:118-119) in one pass over hidden."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias):
+        _lib.require_cuda(hidden, weight)
+        L = _lib.lib()
+        hidden = hidden.contiguous()
+        N, T, H = hidden.shape
+        w = weight.detach().reshape(-1).contiguous()
+        b = None if bias is None else bias.detach().reshape(-1).contiguous()
+        a = torch.empty(N, T, dtype=torch.float32, device=hidden.device)
+        x = torch.empty(N, H, dtype=torch.float32, device=hidden.device)
+        with _lib.timed("token_pool_fwd"):
+            _lib.check(L.ceeg_token_pool_fwd(hidden.data_ptr(), N, T, H, w.data_ptr(), _lib.ptr(b), a.data_ptr(), x.data_ptr(), _lib.stream()),
+                       "ceeg_token_pool_fwd")
+        ctx.save_for_backward(hidden, w, a)
+        ctx.wshape, ctx.has_bias = weight.shape, bias is not None
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        from .models import _colsum
+        hidden, w, a = ctx.saved_tensors
+        L = _lib.lib()
+        N, T, H = hidden.shape
+        g = g.contiguous()
+        dh = torch.empty_like(hidden) if ctx.needs_input_grad[0] else None
+        dw_part = torch.empty(N, H, dtype=torch.float32, device=hidden.device)
+        db_part = torch.empty(N, 4, dtype=torch.float32, device=hidden.device)
+        with _lib.timed("token_pool_bwd"):
+            _lib.check(L.ceeg_token_pool_bwd(hidden.data_ptr(), N, T, H, w.data_ptr(), a.data_ptr(), g.data_ptr(), _lib.ptr(dh), dw_part.data_ptr(),
+                                             db_part.data_ptr(), _lib.stream()), "ceeg_token_pool_bwd")
+        dw = torch.cat([_colsum(dw_part[:, c0:c0 + 1024]) for c0 in range(0, H, 1024)]).view(ctx.wshape)
+        db = _colsum(db_part)[:1] if ctx.has_bias else None
+        return dh, dw, db
+
+
+def token_attention_pool(hidden, attn):
+    """`attn`: the nn.Linear(H, 1) of the reference's conditioners; hidden [N, T, H] -> [N, H]."""
+    return _TokenPool.apply(hidden, attn.weight, attn.bias)

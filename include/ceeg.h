@@ -392,6 +392,17 @@ int ceeg_ancestor_subgraph_count(const int32_t* rowptr, const int32_t* col, cons
 int ceeg_ancestor_subgraph_fill(const int32_t* rowptr, const int32_t* col, const int32_t* anc, const int32_t* cnt, int64_t T, int cap,
                                 const int64_t* slot_off, int32_t* sub_src, int32_t* sub_dst, void* stream);
 
+/* N4  Learned-attention token pooling of the reference's conditioners (scripts/models.py:118-119; the same pair of lines at
+ * :138-139 and :170-171): attn = nn.Linear(H, 1); x = bmm(hidden.permute(0,2,1), attn(hidden)).squeeze(2), i.e.
+ *   a[n,t] = <hidden[n,t,:], w> + b,   x[n,:] = sum_t a[n,t] hidden[n,t,:]        hidden [N, T, H] contiguous fp32
+ * in ONE pass over hidden (one workgroup per node; tokens summed in ascending order).  a [N, T] is an output the backward
+ * takes back.  Backward: da[n,t] = <g[n,:], hidden[n,t,:]>; dhidden[n,t,:] = a[n,t] g[n,:] + da[n,t] w (NULL: not wanted);
+ * dw_part [N, H] / db_part [N, 4] are per-node partials of dw = sum_{n,t} da hidden and db = sum da (column 0) which the caller
+ * reduces over nodes with ceeg_colsum (fixed order).  H % 4 == 0, T <= 512, 16-byte aligned pointers; b may be NULL. */
+int ceeg_token_pool_fwd(const float* hidden, int64_t N, int T, int H, const float* w, const float* b, float* a, float* x, void* stream);
+int ceeg_token_pool_bwd(const float* hidden, int64_t N, int T, int H, const float* w, const float* a, const float* g, float* dhidden,
+                        float* dw_part, float* db_part, void* stream);
+
 /* negative_sampling(edge_index, num_nodes, num_neg_samples) — upstream PyG (python `random`, cannot be
  * matched): uniform variant.  k-th sample: (src,dst) = Philox4x32-10(seed, k, attempt) mod N, rejected
  * when src==dst or src->dst is an edge of the given CSR (rows=dst, src-sorted), up to 16 attempts; a

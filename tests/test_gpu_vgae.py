@@ -742,6 +742,34 @@ def test_decoder_code_form_with_condition_columns():
     _close(zc.grad[:, :D], z64.grad)
 
 
+@pytest.mark.parametrize("N,T,H", [(37, 60, 768), (5, 1, 4), (130, 7, 48), (3, 300, 1100)])
+def test_token_attention_pool_kernels(N, T, H):
+    """ceeg_token_pool_fwd / _bwd vs the reference's two lines (scripts/models.py:118-119) in fp64: output and the gradients of
+    hidden, attn.weight, attn.bias; the reference's own shape (60 tokens x 768) included; bitwise reproducible."""
+    from causal_eeg_vae_amd.pool import token_attention_pool
+    torch.manual_seed(N + T)
+    attn = torch.nn.Linear(H, 1)
+    hidden, r = torch.randn(N, T, H), torch.randn(N, H)
+    a64 = to64(attn)
+    h64 = hidden.double().requires_grad_(True)
+    ref = torch.bmm(h64.permute(0, 2, 1), a64(h64)).squeeze(2)
+    (ref * r.double()).sum().backward()
+    attn = attn.cuda()
+    outs = []
+    for _ in range(2):
+        attn.zero_grad(set_to_none=True)
+        hc = hidden.clone().cuda().requires_grad_(True)
+        out = token_attention_pool(hc, attn)
+        (out * r.cuda()).sum().backward()
+        outs.append((out.detach(), hc.grad, attn.weight.grad.clone(), attn.bias.grad.clone()))
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    _close(outs[0][0], ref)
+    _close(outs[0][1], h64.grad)
+    _close(outs[0][2], a64.weight.grad)
+    _close(outs[0][3], a64.bias.grad)
+
+
 def test_graph_conditioner_vs_oracle():
     """The reference's GraphConditioner (scripts/models.py:95-122; SURVEY.md section 8(f) N1 + N4) end to end on a collated
     batch: token attention pooling -> 3 x [GATConv -> graph LayerNorm -> ReLU] -> GlobalAttention, with a stand-in token
