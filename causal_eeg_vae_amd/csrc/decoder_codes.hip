@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void dc_gram_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
                                                            int64_t sig_a, int64_t sig_b, int64_t sig_mod, const float* __restrict__ row_add,
-                                                           uint4* __restrict__ rec, float* __restrict__ part) {
+                                                           uint4* __restrict__ rec, float* __restrict__ part, int no_neg) {
   const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t row0 = w * 64;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
       if (live) {
         float tp, cp, tn, cn;
         dc_terms(gr[kc] + g_add, gs[kc] + g_add, tp, cp, tn, cn);
-        const bool valid = c != g_sr && !hit;
+        const bool valid = !no_neg && c != g_sr && !hit;
         if (!valid) { tn = 0.f; cn = 0.f; }
         rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)g_kr | ((unsigned)g_ksr << 16), (unsigned)kc);
         a_pos += tp;
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int4* __restrict__ items, int64_t n_items, int64_t sig_a, int64_t sig_b,
                                                            int64_t sig_mod, const float* __restrict__ row_add, uint4* __restrict__ rec,
-                                                           float* __restrict__ part, int64_t slot0) {
+                                                           float* __restrict__ part, int64_t slot0, int no_neg) {
   const int lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n_items) return;
@@ -203,7 +203,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
       const int kc = dc_clamp_code(code[c], K);
       float tp, cp, tn, cn;
       dc_terms(gr[kc] + radd, gs[kc] + radd, tp, cp, tn, cn);
-      const bool valid = c != sr && !dc_sorted_has(col, slo, shi, c);
+      const bool valid = !no_neg && c != sr && !dc_sorted_has(col, slo, shi, c);
       if (!valid) { tn = 0.f; cn = 0.f; }
       rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)kr | ((unsigned)ksr << 16), (unsigned)kc);
       a_pos += tp;
@@ -509,6 +509,8 @@ extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int 
   if (!W || !code || !rowptr || !sums || N <= 0 || nnz < 0 || (nnz > 0 && (!col || !rec))) return CEEG_EINVAL;
   if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (rec && !ceeg_aligned(rec, 16))) return CEEG_EINVAL;
+  const int no_neg = sig_a == 0;  // sig_a == 0: positives only (every cn = 0, sums[1] = sums[2] = 0); sigma is then the identity
+  if (no_neg) { sig_a = 1; sig_b = 0; }
   if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_a >= sig_mod + (sig_mod == 1) || sig_b < 0 || sig_b >= sig_mod) return CEEG_EINVAL;
   if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
   if (max_row_nnz < 0 || (max_row_nnz > DC_CHUNK && n_long == 0)) return CEEG_EINVAL;  // hub rows need their piece list
@@ -522,15 +524,79 @@ extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int 
   CEEG_CHECK_LAUNCH();
   uint4* r4 = static_cast<uint4*>(rec);
   hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col, N, sig_a, sig_b,
-                     sig_mod, row_add, r4, part);
+                     sig_mod, row_add, r4, part, no_neg);
   CEEG_CHECK_LAUNCH();
   if (n_long > 0) {
     hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col,
-                       reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, row_add, r4, part, nwave);
+                       reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, row_add, r4, part, nwave, no_neg);
     CEEG_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nslot, sums);
   CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+// Edge-list form on a quantised latent: <z_i, z_j> = G[code i][code j] (two 4-byte code loads and one float of the L2-resident
+// Gram matrix per pair instead of two D*4-byte rows).  One thread per pair, grid-stride; block partials in a fixed order.
+namespace {
+constexpr int DC_EDGE_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void dc_edge_fwd_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+                                                          const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int negative,
+                                                          float* __restrict__ coef, float* __restrict__ part) {
+  __shared__ float red[2][4];
+  float acc = 0.f, cnt = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    const int ni = ei[e], nj = ej[e];
+    float c = 0.f;
+    if (ni >= 0 && nj >= 0) {  // a pair with a negative id is a sample the sampler gave up on: skipped
+      const float v = G[(size_t)dc_clamp_code(code[ni], K) * K + dc_clamp_code(code[nj], K)];
+      float tp, cp, tn, cn;
+      dc_terms(v, v, tp, cp, tn, cn);
+      acc += negative ? tn : tp;
+      c = negative ? cn : cp;
+      cnt += 1.0f;
+    }
+    if (coef) coef[e] = c;
+  }
+  acc = ceeg_wave_sum(acc);
+  cnt = ceeg_wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = acc; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = part + (size_t)blockIdx.x * 3;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    o[2] = 0.f;
+  }
+}
+}  // namespace
+
+extern "C" size_t ceeg_edge_bce_codes_ws_bytes(int64_t E, int n_e) {
+  if (E < 0 || n_e <= 0) return 0;
+  return ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+}
+
+extern "C" int ceeg_edge_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
+                                       int64_t E, int negative, float* coef, float* loss_sum, void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !code || !loss_sum || E < 0 || n_e <= 0 || D <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
+  if (n_e > 4096 || (D % 4) != 0 || (ldw % 4) != 0 || ldw < D) return CEEG_EUNSUPPORTED;
+  if (!ceeg_aligned(W, 16)) return CEEG_EINVAL;
+  if (ws_bytes < ceeg_edge_bce_codes_ws_bytes(E, n_e) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* G = static_cast<float*>(ws);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + ceeg_ws_part((size_t)n_e * n_e, 4));
+  hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
+  CEEG_CHECK_LAUNCH();
+  int64_t nb = (E + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
+  hipLaunchKernelGGL(dc_edge_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, n_e, code, i, j, E, negative & 1, coef, part);
+  CEEG_CHECK_LAUNCH();
+  // dc_finalize_kernel sums 3 columns; column 2 is zero here: out[0] = sum of terms, out[1] = pairs counted
+  float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;  // 3 floats of scratch behind the partials
+  hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
+  CEEG_CHECK_LAUNCH();
+  if (hipMemcpyAsync(loss_sum, tmp, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return CEEG_ELAUNCH;
   return CEEG_OK;
 }
 

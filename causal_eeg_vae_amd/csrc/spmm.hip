@@ -491,6 +491,18 @@ extern "C" int ceeg_spmm_csr(const int32_t* rowptr, const int32_t* col, const fl
                           static_cast<hipStream_t>(stream), ex);
 }
 
+extern "C" int ceeg_spmm_csr_table(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                                   const float* table, int64_t ldt, const int32_t* xidx, int64_t N, int64_t nnz, int F, int accumulate,
+                                   float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream) {
+  if (!xidx) return CEEG_EINVAL;
+  CeegSpmmEx ex;
+  ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
+  ex.xidx = xidx;
+  return ceeg_spmm_launch(rowptr, col, val, vperm, table, ldt, N, nnz, F, nullptr, 0, accumulate, out, ldo, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream), ex);
+}
+
 extern "C" int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                                    const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
                                    int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,

@@ -143,14 +143,21 @@ def _as_graph(g, num_nodes):
     return EventGraph(g, num_nodes)
 
 
-def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1, items=False):
-    """items: False = let the kernel find the long rows; None / int32 [n,4] = the graph's piece list (CsrPair.long_items)."""
+def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1, items=False, xidx=None):
+    """items: False = let the kernel find the long rows; None / int32 [n,4] = the graph's piece list (CsrPair.long_items).
+    xidx (int32 [n_rows]): x is a TABLE and node c's row is x[xidx[c]] (ceeg_spmm_csr_table; no bias / relu there)."""
     L = _lib.lib()
     nnz = col.shape[0]
     F = x.shape[1]
     if out is None:
         out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
     ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
+    if xidx is not None:
+        with _lib.timed(f"spmm_table_F{F}"):
+            _lib.check(L.ceeg_spmm_csr_table(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
+                                             xidx.data_ptr(), n_rows, nnz, F, int(accumulate), out.data_ptr(), out.stride(0), int(max_row),
+                                             ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_spmm_csr_table")
+        return out
     if items is not False and max_row >= 0:
         with _lib.timed(f"spmm_F{F}"):
             _lib.check(L.ceeg_spmm_csr_items(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
@@ -485,25 +492,40 @@ class _EdgeBCE(torch.autograd.Function):
         out = torch.zeros(2, dtype=torch.float32, device=z.device)
         ws = _lib.workspace(L.ceeg_edge_bce_ws_bytes(E, D), z.device)
         src, sidx = (z, None) if table is None else (table.detach().contiguous(), table_idx.contiguous())
-        with _lib.timed("edge_bce_fwd"):
-            _lib.check(L.ceeg_edge_bce_fwd(src.data_ptr(), src.stride(0), _lib.ptr(sidx), i.data_ptr(), j.data_ptr(), E, D, int(negative),
-                                           coef.data_ptr(), None, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
-        ctx.save_for_backward(z, coef)
+        if table is not None and src.shape[0] <= 4096 and os.environ.get("CEEG_EDGE_CODES", "1") == "1":
+            # code form: the dot product of a pair is an entry of the codebook's Gram matrix
+            ws = _lib.workspace(L.ceeg_edge_bce_codes_ws_bytes(E, src.shape[0]), z.device)
+            with _lib.timed("edge_bce_fwd"):
+                _lib.check(L.ceeg_edge_bce_codes_fwd(src.data_ptr(), src.stride(0), src.shape[0], D, sidx.data_ptr(), i.data_ptr(), j.data_ptr(), E,
+                                                     int(negative), coef.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                           "ceeg_edge_bce_codes_fwd")
+        else:
+            with _lib.timed("edge_bce_fwd"):
+                _lib.check(L.ceeg_edge_bce_fwd(src.data_ptr(), src.stride(0), _lib.ptr(sidx), i.data_ptr(), j.data_ptr(), E, D, int(negative),
+                                               coef.data_ptr(), None, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_edge_bce_fwd")
+        if table is not None:
+            ctx.save_for_backward(src, coef, sidx)
+        else:
+            ctx.save_for_backward(z, coef)
+        ctx.shape = (N, D)
         ctx.edge_index, ctx.pair = edge_index, pair
         ctx.mark_non_differentiable(out[1])
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g, _gc):
-        z, coef = ctx.saved_tensors
-        N = z.shape[0]
+        if len(ctx.saved_tensors) == 3:
+            z, coef, xidx = ctx.saved_tensors   # z = the codebook, rows through the code index (bitwise the same sums)
+        else:
+            (z, coef), xidx = ctx.saved_tensors, None
+        N = ctx.shape[0]
         # the CSR of a fresh edge list (sampled negatives) is built here, once per step: a stable sort by (dst, src) on the
         # device; skipped pairs (negative ids) carry coef 0, so any in-range endpoint will do for them
         pair = ctx.pair if ctx.pair is not None else CsrPair(ctx.edge_index.clamp(min=0), N, self_loops=False)
         # CSR rows = edge_index[1] (j), cols = edge_index[0] (i); perm maps CSR position -> edge id
         cv = coef[pair.perm.long()] * g
-        dz = _spmm(pair.rowptr, pair.col, cv, None, z, N, max_row=pair.max_row)
-        _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True, max_row=pair.max_trow)
+        dz = _spmm(pair.rowptr, pair.col, cv, None, z, N, max_row=pair.max_row, xidx=xidx)
+        _spmm(pair.t_rowptr, pair.t_col, cv, pair.t_perm, z, N, out=dz, accumulate=True, max_row=pair.max_trow, xidx=xidx)
         return dz, None, None, None, None, None
 
 
@@ -647,6 +669,8 @@ class _FusedDecoder(torch.autograd.Function):
         p = ctx.graph.dec
         sidx = ctx.sidx
         a, b, ainv, mod = ctx.sig
+        if a == 0:  # positives only (code form): every cn is 0; sigma is the identity for the backward's addressing
+            a, b, ainv = 1, 0, 1
         gscale = (inv * g).contiguous()
         dz = torch.empty(N, D, dtype=torch.float32, device=z.device)
         if ctx.codes:
@@ -781,9 +805,16 @@ class VGAEVQ(nn.Module):
             if neg_edge_index is None:
                 neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
             W, code = self.vector_quantization.embedding.weight, idx.view(-1).to(torch.int32)
-            ps, pc = _EdgeBCE.apply(z_q, graph.edge_index_i32(), False, graph.dec, W, code)
+            if (os.environ.get("CEEG_DEC_CODES", "1") == "1" and graph.num_edges > 0
+                    and _lib.lib().ceeg_decoder_codes_supported(int(W.shape[0]), int(W.shape[1])) == 1):
+                # positives: the CSR-ordered code-form decoder with its negatives switched off (sig_a = 0)
+                pos, psums = _FusedDecoder.apply(z_q, graph, 0, 0, 1, True, None, W, code)
+                ps = psums[0]
+            else:
+                ps, pc = _EdgeBCE.apply(z_q, graph.edge_index_i32(), False, graph.dec, W, code)
+                pos = ps / pc.clamp(min=1.0)
             ns, nc = _EdgeBCE.apply(z_q, neg_edge_index, True, None, W, code)
-            rec = ps / pc.clamp(min=1.0) + ns / nc.clamp(min=1.0)
+            rec = pos + ns / nc.clamp(min=1.0)
             sums = torch.stack([ps.detach(), ns.detach(), nc])
         else:
             a, b, ainv = sigma_params(N, self.seed, step) if sigma is None else sigma

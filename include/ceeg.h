@@ -151,6 +151,13 @@ int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* 
                         int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,
                         int64_t n_long, void* ws, size_t ws_bytes, void* stream);
 
+/* ceeg_spmm_csr whose gathered matrix is a TABLE read through a row index: out[i,:] (+)= sum_p v(p) * table[xidx[col[p]], :].
+ * For a quantised latent (z[n] = codebook[code[n]] bit for bit) this is the same sum as gathering z itself - bitwise equal -
+ * with the rows coming from a few hundred KB that stay in L2 (the backward of the edge-list decoder over sampled negatives). */
+int ceeg_spmm_csr_table(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                        const float* table, int64_t ldt, const int32_t* xidx, int64_t N, int64_t nnz, int F, int accumulate,
+                        float* out, int64_t ldo, int64_t max_row_nnz, void* ws, size_t ws_bytes, void* stream);
+
 /* Measurement entry (no reference counterpart; used by bench.py / scripts/spmm_probe.py, never by the model): the SpMM row
  * kernel's traversal with everything but the row gathers removed - no value stream, no FMAs, no epilogue, no output.  Its
  * time is the empirical ceiling of a whole-row gather SpMM on this graph.  mode bit 0: gather the entries with
@@ -256,6 +263,7 @@ int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, con
  * z[n] = W[code[n]] bit for bit).  Same pairs, masks, terms and sums as ceeg_decoder_fused_fwd/_bwd (upstream PyG
  * InnerProductDecoder + GAE.recon_loss, literal "+EPS" form), evaluated through the codebook:
  *   forward : G = W W^T (n_e x n_e, k-ascending fmaf chains) once per call; <z_i, z_j> = G[code i][code j];
+ *             sig_a == 0 means POSITIVES ONLY (every cn = 0, sums[1] = sums[2] = 0; the backward then takes sig_a = 1, sig_b = 0);
  *             rec[p] = { cp[p], cn[p] (0 when the negative is masked), code[r] | code[sigma r] << 16, code[col p] }
  *             for CSR entry p of row r (16 bytes, uint32 x 4; cp/cn as float bits); sums[0..2] as the fused decoder.
  *   backward: dz[n] = gp*(sum_{p in row n} cp W[kc] + sum_{q in trow n} cp[tperm q] W[kr]) +
@@ -271,6 +279,12 @@ int ceeg_decoder_fused_bwd(const float* z, int64_t ldz, const int32_t* zidx, con
  * |c_graph(r)|^2 - pass it as row_add[r] (float [N], NULL = 0); the backward's coef_sum[n] (float [N], NULL = not wanted)
  * is the summed, scaled coefficient of all pairs of node n, so d loss / d condition_columns[n] = coef_sum[n] * c_graph(n).
  * No counterpart in the reference beyond A6 itself; an algebraic re-association for the quantised case. */
+/* The edge-list form (ceeg_edge_bce_fwd) on a quantised latent in code form: v_e = G[code i_e][code j_e] with G = W W^T rebuilt per
+ * call (as ceeg_decoder_codes_fwd).  Same terms, skipping rule and outputs (coef[e], loss_sum = {sum of terms, pairs counted});
+ * the dot products differ from the row-gather form only by the summation order of the fmaf chain.  n_e <= 4096, D % 4 == 0. */
+size_t ceeg_edge_bce_codes_ws_bytes(int64_t E, int n_e);
+int ceeg_edge_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
+                            int64_t E, int negative, float* coef, float* loss_sum, void* ws, size_t ws_bytes, void* stream);
 int ceeg_decoder_codes_chunk(void);
 int ceeg_decoder_codes_supported(int n_e, int D);
 size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);

@@ -185,13 +185,20 @@ def test_full_step_vs_oracle():
     _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), {})
 
 
-def test_full_step_uniform_negatives_vs_oracle():
-    """The literal path of the north star: recon_loss over the positive edges and E pairs drawn by negative_sampling
+@pytest.mark.parametrize("forms", ["codes", "rows"])
+def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
+    """forms = "codes": positives through the code-form fused decoder with its negatives switched off, sampled negatives through
+    the Gram-matrix edge kernel and table-form SpMMs; "rows": every pair list through the row-gather edge kernel (table rows)
+    and SpMMs - the checker form.  Both against the fp64 oracle.
+    The literal path of the north star: recon_loss over the positive edges and E pairs drawn by negative_sampling
     (ceeg_neg_sample_uniform) every step.  The GPU's samples are bit-exact with the C oracle's Philox stream; loss and every
     parameter gradient against the fp64 oracle fed the same explicit negatives; a second call with given negatives of
     which some are (-1, -1) (samples the sampler gave up on) checks that such pairs are skipped and not counted."""
     from causal_eeg_vae_amd import VGAEVQ, EventGraph
     from oracle import c_oracle, ref_torch
+    if forms == "rows":
+        monkeypatch.setenv("CEEG_DEC_CODES", "0")
+        monkeypatch.setenv("CEEG_EDGE_CODES", "0")
     N, E, Fi, D, n_e = 3000, 48000, 32, 64, 128
     ei_np = _graph(N, E, 7)
     torch.manual_seed(0)
