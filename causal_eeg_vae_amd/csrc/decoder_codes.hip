@@ -18,6 +18,7 @@
 // One 16-lane group (a DPP row) owns a row / node: entries are held one per lane and broadcast inside the group with
 // row_newbcast (no LDS traffic for the shuffles), four rows per wave in flight.  No float atomics; every sum has a
 // fixed order (entry order inside a list, lists in the order above, long lists in ascending 256-entry pieces).
+#include <rocprim/device/device_radix_sort.hpp>
 #include "ceeg_internal.h"
 
 namespace {
@@ -292,9 +293,9 @@ __device__ __forceinline__ void dc_batch2(const float4* lds4, int gl, float ca, 
 }
 #undef DC_STEP2
 
-__device__ __forceinline__ void dc_fill_slab(const DcGradArgs& a, int slab, float4* lds4) {
-  for (int i = threadIdx.x; i < a.K * 16; i += DC_GRAD_THREADS)
-    lds4[i] = *reinterpret_cast<const float4*>(a.W + (int64_t)(i >> 4) * a.ldw + slab * DC_CW + 4 * (i & 15));
+__device__ __forceinline__ void dc_fill_slab(const float* __restrict__ W, int64_t ldw, int K, int slab, float4* lds4) {
+  for (int i = threadIdx.x; i < K * 16; i += DC_GRAD_THREADS)
+    lds4[i] = *reinterpret_cast<const float4*>(W + (int64_t)(i >> 4) * ldw + slab * DC_CW + 4 * (i & 15));
   __syncthreads();
 }
 
@@ -309,12 +310,14 @@ __device__ __forceinline__ void dc_add_pieces(const float* __restrict__ part, in
 
 // Persistent grid, one workgroup per CU; workgroup b sweeps slab b % nslab.  Every wave draws 64 consecutive nodes from its
 // slab's counter (integer atomics only: which wave computes a node does not change the node's result).
+// NEG = false: positives only (every cn is 0): the sigma-row list and the cn halves of the transposed list are not walked.
+template <bool NEG>
 __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* lds4 = reinterpret_cast<float4*>(smem);
   const int nslab = a.D / DC_CW;
   const int slab = blockIdx.x % nslab;
-  dc_fill_slab(a, slab, lds4);
+  dc_fill_slab(a.W, a.ldw, a.K, slab, lds4);
   const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
   const int col0 = slab * DC_CW + 4 * gl;
   const float gp = a.gscale[0], gn = a.gscale[1];
@@ -330,9 +333,11 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
     if (n < a.N) {
       alo = a.rowptr[n];
       ahi = a.rowptr[n + 1];
-      const int64_t m = dc_sigma_inv(n, a.sig_ainv, a.sig_b, a.sig_mod);
-      blo = a.rowptr[m];
-      bhi = a.rowptr[m + 1];
+      if (NEG) {
+        const int64_t m = dc_sigma_inv(n, a.sig_ainv, a.sig_b, a.sig_mod);
+        blo = a.rowptr[m];
+        bhi = a.rowptr[m + 1];
+      }
       clo = a.t_rowptr[n];
       chi = a.t_rowptr[n + 1];
     }
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       s.ra = zero4; s.rb = zero4; s.rc = zero4;
       if (s.C_lo + gl < s.c_hi) s.rc = a.rec[s.tp];
       if (s.A_lo + gl < s.a_hi) s.ra = a.rec[s.A_lo + gl];
-      if (s.B_lo + gl < s.b_hi) s.rb = a.rec[s.B_lo + gl];
+      if (NEG && s.B_lo + gl < s.b_hi) s.rb = a.rec[s.B_lo + gl];
     };
     bounds(0, s0);
     bounds(1, s1);
@@ -375,7 +380,7 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
         dc_batch1(lds4, gl, __uint_as_float(ra.x), (int)ra.w, nb < 0 ? 0 : nb, s1v);
       }
       // (3) n as negative endpoint sigma(m): sum_{p in row m} cn W[kc]
-      for (int base = s0.B_lo; __any(base < s0.b_hi); base += 16) {
+      for (int base = s0.B_lo; NEG && __any(base < s0.b_hi); base += 16) {
         if (base != s0.B_lo) { rb = zero4; if (base + gl < s0.b_hi) rb = a.rec[base + gl]; }
         const int nb = s0.b_hi - base;
         dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3v);
@@ -387,13 +392,14 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
           if (base + gl < s0.c_hi) rc = a.rec[a.t_perm[base + gl]];
         }
         const int nb = s0.c_hi - base;
-        dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2v, s4v);
+        if (NEG) dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2v, s4v);
+        else dc_batch1(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), nb < 0 ? 0 : nb, s2v);
       }
       if (s0.A_hi != s0.a_hi) dc_add_pieces(a.part_csr, s0.A_lo, s0.A_hi, 0, a.D, col0, s1v);
-      if (s0.B_hi != s0.b_hi) dc_add_pieces(a.part_csr, s0.B_lo, s0.B_hi, 1, a.D, col0, s3v);
+      if (NEG && s0.B_hi != s0.b_hi) dc_add_pieces(a.part_csr, s0.B_lo, s0.B_hi, 1, a.D, col0, s3v);
       if (s0.C_hi != s0.c_hi) {
         dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 0, a.D, col0, s2v);
-        dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 1, a.D, col0, s4v);
+        if (NEG) dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 1, a.D, col0, s4v);
       }
       if (j < cnt) {
         float4 o;
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_long_kernel(DcGradArg
   float4* lds4 = reinterpret_cast<float4*>(smem);
   const int nslab = a.D / DC_CW;
   const int slab = blockIdx.x % nslab;
-  dc_fill_slab(a, slab, lds4);
+  dc_fill_slab(a.W, a.ldw, a.K, slab, lds4);
   const int gl = threadIdx.x & 15;
   const int col0 = slab * DC_CW + 4 * gl;
   const int64_t stride = (int64_t)(gridDim.x / nslab) * (DC_GRAD_THREADS / 16);
@@ -609,6 +615,8 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
   if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) || (rec && !ceeg_aligned(rec, 16)))
     return CEEG_EINVAL;
+  const bool no_neg = sig_a == 0;  // positives only, as ceeg_decoder_codes_fwd: sigma is then the identity
+  if (no_neg) { sig_a = 1; sig_b = 0; sig_ainv = 1; }
   if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_b < 0 || sig_b >= sig_mod || sig_ainv <= 0) return CEEG_EINVAL;
   if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)sig_mod) != (uint64_t)(1 % sig_mod)) return CEEG_EINVAL;
   if (n_long < 0 || n_tlong < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16))) ||
@@ -646,11 +654,254 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
                        reinterpret_cast<const int4*>(t_long_items), n_tlong);
     CEEG_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(dc_grad_rows_kernel, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
+  if (no_neg) hipLaunchKernelGGL(dc_grad_rows_kernel<false>, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
+  else hipLaunchKernelGGL(dc_grad_rows_kernel<true>, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
   CEEG_CHECK_LAUNCH();
   if (coef_sum) {
     hipLaunchKernelGGL(dc_coef_sum_kernel, dim3((unsigned)(((N + 63) / 64 + 3) / 4)), dim3(256), 0, st, a, coef_sum);
     CEEG_CHECK_LAUNCH();
   }
+  return CEEG_OK;
+}
+
+// ================================================================================================ pair lists on a quantised latent
+// recon_loss over an ARBITRARY pair list (the negatives `negative_sampling` draws afresh every step) without building a CSR pair:
+//   forward : per pair k = (i, j): v = G[code i][code j], term and c = d term / dv; two INCIDENCE records are written,
+//             (key j, (c, code i)) and (key i, (c, code j)) - row `key` of the gradient receives c * W[code];
+//   backward: ONE stable radix sort of the 2E (32-bit key, 64-bit record) incidences groups them by node (incidence order kept
+//             inside a node: a fixed summation order, no float atomics), a boundary scan gives the row pointers, and
+//             dc_pair_grad_kernel sums c * W[code] from the LDS codebook slab: dz[n] (+)= gscale * sum.
+// Pairs with an id outside [0, N) are skipped (not counted, key N: sorted behind every node).
+namespace {
+
+unsigned dc_key_bits(int64_t N) {  // bits that hold the value N itself (the key of skipped pairs)
+  unsigned b = 1;
+  while (((int64_t)1 << b) <= N) ++b;
+  return b;
+}
+size_t dc_pair_sort_temp(size_t M, unsigned end_bit) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  uint64_t* v = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, M, 0u, end_bit, (hipStream_t)0, false) != hipSuccess) return 0;
+  return bytes < 256 ? 256 : bytes;
+}
+
+__global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+                                                          const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int64_t N,
+                                                          int negative, uint2* __restrict__ keys, ulonglong2* __restrict__ recs,
+                                                          float* __restrict__ part) {
+  __shared__ float red[2][4];
+  float acc = 0.f, cnt = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    const int ni = ei[e], nj = ej[e];
+    float c = 0.f;
+    unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
+    if (ni >= 0 && nj >= 0 && ni < N && nj < N) {
+      ki = (unsigned)dc_clamp_code(code[ni], K);
+      kj = (unsigned)dc_clamp_code(code[nj], K);
+      const float v = G[(size_t)ki * K + kj];
+      float tp, cp, tn, cn;
+      dc_terms(v, v, tp, cp, tn, cn);
+      acc += negative ? tn : tp;
+      c = negative ? cn : cp;
+      cnt += 1.0f;
+      key_i = (unsigned)ni;
+      key_j = (unsigned)nj;
+    }
+    if (keys) {
+      const unsigned long long cb = (unsigned long long)__float_as_uint(c);
+      keys[e] = make_uint2(key_j, key_i);
+      recs[e] = make_ulonglong2(cb | ((unsigned long long)ki << 32), cb | ((unsigned long long)kj << 32));
+    }
+  }
+  acc = ceeg_wave_sum(acc);
+  cnt = ceeg_wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = acc; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = part + (size_t)blockIdx.x * 3;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    o[2] = 0.f;
+  }
+}
+
+// sorted keys -> row pointers: thread p closes every row between key[p-1] and key[p] (keys >= N count as N)
+__global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint32_t* __restrict__ keys, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p > M) return;
+  int64_t cur = N, prev = -1;
+  if (p < M) { const int64_t k = (int64_t)keys[p]; cur = k < N ? k : N; }
+  if (p > 0) { const int64_t k = (int64_t)keys[p - 1]; prev = k < N ? k : N; }
+  for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)p;
+}
+
+struct DcPairGradArgs {
+  const float* W;
+  int64_t ldw;
+  int K, D;
+  const int32_t* rowptr;
+  const uint64_t* recs;
+  const float* gscale;
+  float* dz;
+  int64_t lddz, N;
+  int accumulate;
+  unsigned int* queue;
+};
+
+// Persistent grid as dc_grad_rows_kernel: one workgroup per CU holds a 64-column codebook slab in LDS; a wave draws 64
+// consecutive nodes, a 16-lane group owns a node and walks its incidence list 16 records at a time (the first batch of the
+// next node is in flight while this one is summed).
+__global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4* lds4 = reinterpret_cast<float4*>(smem);
+  const int nslab = a.D / DC_CW;
+  const int slab = blockIdx.x % nslab;
+  dc_fill_slab(a.W, a.ldw, a.K, slab, lds4);
+  const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
+  const int col0 = slab * DC_CW + 4 * gl;
+  const float gs = a.gscale[0];
+  unsigned int* q = a.queue + slab * 32;
+  for (;;) {
+    unsigned int dv = 0;
+    if (lane == 0) dv = atomicAdd(q, 64u);
+    const int64_t base_n = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
+    if (base_n >= a.N) break;
+    const int64_t n = base_n + lane;
+    int lo = 0, hi = 0;
+    if (n < a.N) {
+      lo = a.rowptr[n];
+      hi = a.rowptr[n + 1];
+    }
+    const int cnt = a.N - base_n < 64 ? (int)(a.N - base_n) : 64;
+    int n_lo = __shfl(lo, grp, 64), n_hi = __shfl(hi, grp, 64);
+    unsigned long long n_rec = 0ull;
+    if (n_lo + gl < n_hi) n_rec = a.recs[n_lo + gl];
+    for (int it = 0; it * 4 < cnt; ++it) {
+      const int j = it * 4 + grp;
+      const int A_lo = n_lo, A_hi = n_hi;
+      unsigned long long r = n_rec;
+      {  // first batch of the next node
+        const int jn = (j + 4) & 63;
+        const bool ok = (it + 1) * 4 < cnt;  // wave-uniform
+        n_lo = __shfl(lo, jn, 64);
+        n_hi = __shfl(hi, jn, 64);
+        if (!ok) n_hi = n_lo;
+        n_rec = 0ull;
+        if (n_lo + gl < n_hi) n_rec = a.recs[n_lo + gl];
+      }
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int base = A_lo; __any(base < A_hi); base += 16) {
+        if (base != A_lo) { r = 0ull; if (base + gl < A_hi) r = a.recs[base + gl]; }
+        const int nb = A_hi - base;
+        dc_batch1(lds4, gl, __uint_as_float((unsigned)(r & 0xffffffffull)), (int)(r >> 32), nb < 0 ? 0 : nb, s);
+      }
+      if (j < cnt) {
+        float* op = a.dz + (base_n + j) * a.lddz + col0;
+        float4 o = make_float4(gs * s.x, gs * s.y, gs * s.z, gs * s.w);
+        if (a.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(op);
+          o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+        }
+        *reinterpret_cast<float4*>(op) = o;
+      }
+    }
+  }
+}
+
+struct DcPairWs {
+  uint32_t* keys_out;
+  uint64_t* recs_out;
+  int32_t* rowptr;
+  unsigned int* queue;
+  void* temp;
+  size_t temp_bytes;
+};
+size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPairWs* out) {
+  const size_t M = (size_t)(2 * E);
+  const size_t tb = dc_pair_sort_temp(M, dc_key_bits(N));
+  if (tb == 0) return 0;
+  const size_t need = ceeg_ws_part(M, 4) + ceeg_ws_part(M, 8) + ceeg_ws_part((size_t)N + 1, 4) + 1024 + ceeg_align_up(tb, 256);
+  if (out) {
+    CeegWs a(ws, ws_bytes);
+    out->keys_out = a.take<uint32_t>(M);
+    out->recs_out = a.take<uint64_t>(M);
+    out->rowptr = a.take<int32_t>((size_t)N + 1);
+    out->queue = a.take<unsigned int>(256);
+    out->temp = a.take<char>(tb);
+    out->temp_bytes = tb;
+    if (!a.ok) return 0;
+  }
+  return need;
+}
+
+}  // namespace
+
+extern "C" size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e) {
+  if (E < 0 || N <= 0 || n_e <= 0 || E >= ((int64_t)1 << 30)) return 0;
+  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+  const size_t bwd = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
+  return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
+                                       int64_t E, int64_t N, int negative, uint32_t* keys, uint64_t* recs, float* loss_sum, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (!W || !code || !loss_sum || E < 0 || N <= 0 || (E > 0 && (!i || !j)) || ((keys == nullptr) != (recs == nullptr))) return CEEG_EINVAL;
+  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 30)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && (!ceeg_aligned(keys, 8) || !ceeg_aligned(recs, 16)))) return CEEG_EINVAL;
+  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+  if (ws_bytes < fwd || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* G = static_cast<float*>(ws);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + ceeg_ws_part((size_t)n_e * n_e, 4));
+  hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
+  CEEG_CHECK_LAUNCH();
+  int64_t nb = (E + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
+  hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, n_e, code, i, j, E, N, negative & 1,
+                     reinterpret_cast<uint2*>(keys), reinterpret_cast<ulonglong2*>(recs), part);
+  CEEG_CHECK_LAUNCH();
+  float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
+  hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
+  CEEG_CHECK_LAUNCH();
+  if (hipMemcpyAsync(loss_sum, tmp, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return CEEG_ELAUNCH;
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint32_t* keys, const uint64_t* recs, int64_t E,
+                                       int64_t N, const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!W || !gscale || !dz || E < 0 || N <= 0 || (E > 0 && (!keys || !recs))) return CEEG_EINVAL;
+  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 30)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) ||
+      (recs && !ceeg_aligned(recs, 8)))
+    return CEEG_EINVAL;
+  DcPairWs w;
+  const size_t need = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
+  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (dc_pair_bwd_layout(E, N, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t M = 2 * E;
+  if (M > 0) {
+    size_t tb = w.temp_bytes;
+    if (rocprim::radix_sort_pairs(w.temp, tb, keys, w.keys_out, recs, w.recs_out, (size_t)M, 0u, dc_key_bits(N), st, false) != hipSuccess)
+      return CEEG_ELAUNCH;
+  }
+  hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
+  CEEG_CHECK_LAUNCH();
+  if (hipMemsetAsync(w.queue, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
+  DcPairGradArgs a;
+  a.W = W; a.ldw = ldw; a.K = n_e; a.D = D;
+  a.rowptr = w.rowptr; a.recs = w.recs_out; a.gscale = gscale;
+  a.dz = dz; a.lddz = lddz; a.N = N; a.accumulate = accumulate ? 1 : 0; a.queue = w.queue;
+  const int nslab = D / DC_CW;
+  int64_t per_slab = (N + (DC_GRAD_THREADS / 16) - 1) / (DC_GRAD_THREADS / 16);
+  const int64_t cap = DC_MAX_GRAD_BLOCKS / nslab;
+  per_slab = per_slab < 1 ? 1 : (per_slab > cap ? cap : per_slab);
+  hipLaunchKernelGGL(dc_pair_grad_kernel, dim3((unsigned)(per_slab * nslab)), dim3(DC_GRAD_THREADS), (size_t)n_e * DC_CW * 4, st, a);
+  CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

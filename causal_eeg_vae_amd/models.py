@@ -529,6 +529,53 @@ class _EdgeBCE(torch.autograd.Function):
         return dz, None, None, None, None, None
 
 
+class _PairBCECodes(torch.autograd.Function):
+    """(sum_k term_k, pairs counted) over an arbitrary pair list on a QUANTISED latent (ceeg_pair_bce_codes_fwd / _bwd): dots
+    from the codebook's Gram matrix; the backward groups the 2E incidences by node with one device radix sort and sums
+    c * W[code] from an LDS codebook slab - no CSR pair of the list, no host sync, no float atomics."""
+
+    @staticmethod
+    def supported(table):
+        return _lib.lib().ceeg_decoder_codes_supported(int(table.shape[0]), int(table.shape[1])) == 1
+
+    @staticmethod
+    def forward(ctx, z, edge_index, negative, table, table_idx):
+        _lib.require_cuda(z, edge_index)
+        L = _lib.lib()
+        N, D = z.shape
+        W, code = table.detach().contiguous(), table_idx.contiguous()
+        i, j = _edge_lists_i32(edge_index)
+        E = i.shape[0]
+        out = torch.zeros(2, dtype=torch.float32, device=z.device)
+        want = ctx.needs_input_grad[0]
+        keys = torch.empty(max(2 * E, 2), dtype=torch.int32, device=z.device) if want else None
+        recs = torch.empty(max(2 * E, 2), dtype=torch.int64, device=z.device) if want else None
+        ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, W.shape[0]), z.device)
+        with _lib.timed("pair_bce_fwd"):
+            _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), W.shape[0], D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N,
+                                                 int(negative), _lib.ptr(keys), _lib.ptr(recs), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _lib.stream()), "ceeg_pair_bce_codes_fwd")
+        if want:
+            ctx.save_for_backward(W, keys, recs)
+        ctx.shape, ctx.E = (N, D), E
+        ctx.mark_non_differentiable(out[1])
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        W, keys, recs = ctx.saved_tensors
+        L = _lib.lib()
+        N, D = ctx.shape
+        dz = torch.empty(N, D, dtype=torch.float32, device=W.device)
+        gs = g.detach().to(torch.float32).reshape(1).contiguous()
+        ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(ctx.E, N, W.shape[0]), W.device)
+        with _lib.timed("pair_bce_bwd"):
+            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), W.shape[0], D, keys.data_ptr(), recs.data_ptr(), ctx.E, N,
+                                                 gs.data_ptr(), 0, dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
+                       "ceeg_pair_bce_codes_bwd")
+        return dz, None, None, None, None
+
+
 class InnerProductDecoder(nn.Module):
     """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge (sigmoid=False: the raw inner product).  Inference-only: it
     carries no autograd path - training goes through VGAE.recon_loss, whose loss and gradient are fused kernels."""
@@ -669,8 +716,8 @@ class _FusedDecoder(torch.autograd.Function):
         p = ctx.graph.dec
         sidx = ctx.sidx
         a, b, ainv, mod = ctx.sig
-        if a == 0:  # positives only (code form): every cn is 0; sigma is the identity for the backward's addressing
-            a, b, ainv = 1, 0, 1
+        if a == 0 and not ctx.codes:  # positives only: every cn is 0; sigma is the identity for the backward's addressing
+            a, b, ainv = 1, 0, 1          # (the code form takes a == 0 itself and walks only the positive lists)
         gscale = (inv * g).contiguous()
         dz = torch.empty(N, D, dtype=torch.float32, device=z.device)
         if ctx.codes:
@@ -813,7 +860,10 @@ class VGAEVQ(nn.Module):
             else:
                 ps, pc = _EdgeBCE.apply(z_q, graph.edge_index_i32(), False, graph.dec, W, code)
                 pos = ps / pc.clamp(min=1.0)
-            ns, nc = _EdgeBCE.apply(z_q, neg_edge_index, True, None, W, code)
+            if os.environ.get("CEEG_PAIR_CODES", "1") == "1" and _PairBCECodes.supported(W):
+                ns, nc = _PairBCECodes.apply(z_q, neg_edge_index, True, W, code)   # no CSR of the sampled list: one sort of incidences
+            else:
+                ns, nc = _EdgeBCE.apply(z_q, neg_edge_index, True, None, W, code)
             rec = pos + ns / nc.clamp(min=1.0)
             sums = torch.stack([ps.detach(), ns.detach(), nc])
         else:

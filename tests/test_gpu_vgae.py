@@ -185,9 +185,10 @@ def test_full_step_vs_oracle():
     _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), {})
 
 
-@pytest.mark.parametrize("forms", ["codes", "rows"])
+@pytest.mark.parametrize("forms", ["pairs", "codes", "rows"])
 def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
-    """forms = "codes": positives through the code-form fused decoder with its negatives switched off, sampled negatives through
+    """forms = "pairs" (the default): as "codes", but the sampled negatives go through ceeg_pair_bce_codes_* (one radix sort of
+    the 2E incidences, LDS codebook slab; no CSR of the sampled list); "codes": positives through the code-form fused decoder with its negatives switched off, sampled negatives through
     the Gram-matrix edge kernel and table-form SpMMs; "rows": every pair list through the row-gather edge kernel (table rows)
     and SpMMs - the checker form.  Both against the fp64 oracle.
     The literal path of the north star: recon_loss over the positive edges and E pairs drawn by negative_sampling
@@ -199,6 +200,8 @@ def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
     if forms == "rows":
         monkeypatch.setenv("CEEG_DEC_CODES", "0")
         monkeypatch.setenv("CEEG_EDGE_CODES", "0")
+    if forms != "pairs":
+        monkeypatch.setenv("CEEG_PAIR_CODES", "0")
     N, E, Fi, D, n_e = 3000, 48000, 32, 64, 128
     ei_np = _graph(N, E, 7)
     torch.manual_seed(0)
@@ -227,6 +230,44 @@ def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
     loss2.backward()
     assert int(aux2["dec_sums"][2]) == int((s2 >= 0).sum())
     _check_step_against_fp64_oracle(ref, model, loss2, aux2, (x, ei, eps, neg2.to(torch.int64), torch.from_numpy(s2 >= 0)), {})
+
+
+@pytest.mark.parametrize("N,E,D,n_e,negative", [(1000, 20000, 64, 100, True), (777, 5000, 128, 512, False), (64, 0, 64, 8, True),
+                                                 (130, 9000, 256, 33, True)])
+def test_pair_list_code_form_vs_fp64(N, E, D, n_e, negative):
+    """ceeg_pair_bce_codes_fwd / _bwd on an arbitrary pair list (duplicates, i == j pairs, holes, ids >= N, one hub node with
+    thousands of incidences, N not a multiple of 64, the empty list): sum, count and dz against fp64 torch on the same list;
+    twice in a row bit-identical (the sort is stable: fixed summation order)."""
+    from causal_eeg_vae_amd.models import _PairBCECodes
+    rng = np.random.default_rng(N + E)
+    W = torch.from_numpy(rng.normal(0, 0.4, (n_e, D)).astype(np.float32))
+    code = torch.from_numpy(rng.integers(0, n_e, N).astype(np.int32))
+    i, j = rng.integers(0, N, E), rng.integers(0, N, E)
+    if E:
+        i[: E // 16] = 5                     # hub: a 16th of the pairs share one endpoint (a fp32 chain of ~1000 terms; the sampler
+        j[E // 4: E // 4 + 10] = i[E // 4: E // 4 + 10]     # itself never makes one: rows of a uniform draw are Poisson(2E/N));  i == j
+        i[-7:] = i[-14:-7]; j[-7:] = j[-14:-7]              # duplicates
+        i[3::11] = -1; j[3::11] = -1          # holes
+        j[4::97] = N + 3                      # out of range: skipped as well
+    ei = torch.from_numpy(np.stack([i, j]).astype(np.int64))
+    ok = torch.from_numpy((i >= 0) & (j >= 0) & (i < N) & (j < N))
+    outs = []
+    for _ in range(2):
+        z = W.cuda()[code.cuda().long()].requires_grad_(True)
+        s, c = _PairBCECodes.apply(z, ei.cuda(), negative, W.cuda(), code.cuda())
+        (s * 0.37).backward()
+        outs.append((s.detach().cpu(), c.cpu(), z.grad.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    z64 = W.double()[code.long()].requires_grad_(True)
+    ii, jj = ei[0][ok], ei[1][ok]
+    from oracle import ref_torch
+    p = ref_torch.decode(z64, torch.stack([ii, jj]))          # float64 dots, the fp32 sigmoid's roundings (oracle/ref_torch.py)
+    terms = -torch.log(1 - p + 1e-15) if negative else -torch.log(p + 1e-15)
+    ref = terms.sum()
+    (ref * 0.37).backward()
+    assert int(outs[0][1]) == int(ok.sum())
+    _close(outs[0][0], ref, what="sum")
+    _close(outs[0][2], z64.grad, what="dz")
 
 
 @pytest.mark.parametrize("per_graph,D,n_e", [(True, 12, 32), (False, 12, 32), (True, 64, 100), (False, 64, 100)])
