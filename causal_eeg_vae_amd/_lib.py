@@ -83,6 +83,9 @@ SIGNATURES = {
     "ceeg_token_pool_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp]),
     "ceeg_token_pool_bwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ceeg_neg_sample_uniform": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _vp, _vp]),
+    "ceeg_neg_filter_bits": (_c_int, [_c_i64]),
+    "ceeg_neg_filter_build": (_c_int, [_vp, _vp, _c_i64, _c_int, _vp, _vp]),
+    "ceeg_neg_sample_uniform_filtered": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _c_int, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -121,8 +121,28 @@ __device__ __forceinline__ bool csr_has(const int32_t* __restrict__ rowptr, cons
   return lo < end && col[lo] == s;
 }
 
+// Edge-set prefilter of the sampler: one bit per hash bucket of (src, dst); a clear bit proves "not an edge" with ONE random
+// read instead of the row-pointer pair and the binary search (exact: set bits still go through the search).
+__device__ __forceinline__ uint32_t neg_filter_hash(int32_t s, int32_t d, unsigned bits) {
+  const uint64_t x = (((uint64_t)(uint32_t)d << 32) | (uint64_t)(uint32_t)s) * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(x >> (64 - bits));
+}
+__global__ void neg_filter_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, unsigned bits,
+                                        uint32_t* __restrict__ filter) {
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per row
+  if (r >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  for (int p = lo + lane; p < hi; p += 64) {
+    const uint32_t h = neg_filter_hash(col[p], (int32_t)r, bits);
+    atomicOr(&filter[h >> 5], 1u << (h & 31));  // integer OR: order-independent
+  }
+}
+
+template <bool FILTER>
 __global__ void neg_sample_uniform_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, int64_t num,
-                                          uint64_t seed, int32_t* __restrict__ neg_src, int32_t* __restrict__ neg_dst) {
+                                          uint64_t seed, const uint32_t* __restrict__ filter, unsigned filter_bits,
+                                          int32_t* __restrict__ neg_src, int32_t* __restrict__ neg_dst) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num) return;
   int32_t s = -1, d = -1;
@@ -131,8 +151,17 @@ __global__ void neg_sample_uniform_kernel(const int32_t* __restrict__ rowptr, co
     const int32_t cs = (int32_t)(((uint64_t)x.x * (uint64_t)N) >> 32);
     const int32_t cd = (int32_t)(((uint64_t)x.y * (uint64_t)N) >> 32);
     if (cs == cd) continue;
+    if (FILTER) {
+      const uint32_t h = neg_filter_hash(cs, cd, filter_bits);
+      if (((filter[h >> 5] >> (h & 31)) & 1u) == 0u) {  // clear bit: not an edge
+        s = cs;
+        d = cd;
+        break;
+      }
+    }
     if (csr_has(rowptr, col, cd, cs)) continue;
-    s = cs; d = cd;
+    s = cs;
+    d = cd;
     break;
   }
   neg_src[k] = s;
@@ -264,11 +293,37 @@ extern "C" int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const in
 
 extern "C" int ceeg_neg_sample_uniform(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
                                        int32_t* neg_src, int32_t* neg_dst, void* stream) {
+  return ceeg_neg_sample_uniform_filtered(rowptr, col, N, num, seed, nullptr, 0, neg_src, neg_dst, stream);
+}
+
+extern "C" int ceeg_neg_filter_bits(int64_t nnz) {  // log2 of the bitmap size: >= 16 bits per edge (<= 1/16 of the bits set), 2^13 .. 2^32
+  int b = 13;
+  while (b < 32 && ((int64_t)1 << b) < 16 * nnz) ++b;
+  return b;
+}
+
+extern "C" int ceeg_neg_filter_build(const int32_t* rowptr, const int32_t* col, int64_t N, int bits, uint32_t* filter, void* stream) {
+  if (N <= 0 || !rowptr || !filter || bits < 13 || bits > 32 || !ceeg_aligned(filter, 4)) return CEEG_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(filter, 0, ((size_t)1 << bits) / 8, st) != hipSuccess) return CEEG_ELAUNCH;
+  hipLaunchKernelGGL(neg_filter_build_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, (unsigned)bits, filter);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+extern "C" int ceeg_neg_sample_uniform_filtered(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
+                                                const uint32_t* filter, int filter_bits, int32_t* neg_src, int32_t* neg_dst,
+                                                void* stream) {
   if (N <= 1 || num < 0 || !rowptr || !col || (num > 0 && (!neg_src || !neg_dst))) return CEEG_EINVAL;
+  if (filter && (filter_bits < 13 || filter_bits > 32)) return CEEG_EINVAL;
   if (num == 0) return CEEG_OK;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(neg_sample_uniform_kernel, dim3((unsigned)((num + 255) / 256)), dim3(256), 0, st, rowptr, col, N, num, seed, neg_src,
-                     neg_dst);
+  const dim3 grid((unsigned)((num + 255) / 256));
+  if (filter)
+    hipLaunchKernelGGL(neg_sample_uniform_kernel<true>, grid, dim3(256), 0, st, rowptr, col, N, num, seed, filter, (unsigned)filter_bits,
+                       neg_src, neg_dst);
+  else
+    hipLaunchKernelGGL(neg_sample_uniform_kernel<false>, grid, dim3(256), 0, st, rowptr, col, N, num, seed, filter, 0u, neg_src, neg_dst);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

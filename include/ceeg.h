@@ -441,6 +441,14 @@ int ceeg_token_pool_bwd(const float* hidden, int64_t N, int T, int H, const floa
  * sample that never succeeds is written as (-1,-1).  Bit-exact restatement: oracle/ceeg_oracle.c. */
 int ceeg_neg_sample_uniform(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
                             int32_t* neg_src, int32_t* neg_dst, void* stream);
+/* The same samples, bit for bit, with an edge-set PREFILTER built once per graph: a bitmap of 2^bits bits (bits =
+ * ceeg_neg_filter_bits(nnz): at least 16 bits per edge) with the bit of hash(src, dst) set for every edge.  A candidate whose
+ * bit is clear is not an edge (one random read); only candidates with a set bit take the row's binary search.
+ * filter: uint32 [2^bits / 32]; NULL = no prefilter (= ceeg_neg_sample_uniform). */
+int ceeg_neg_filter_bits(int64_t nnz);
+int ceeg_neg_filter_build(const int32_t* rowptr, const int32_t* col, int64_t N, int bits, uint32_t* filter, void* stream);
+int ceeg_neg_sample_uniform_filtered(const int32_t* rowptr, const int32_t* col, int64_t N, int64_t num, uint64_t seed,
+                                     const uint32_t* filter, int filter_bits, int32_t* neg_src, int32_t* neg_dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -110,10 +110,14 @@ def test_spmm_tiny_graphs(N, E):
         np.testing.assert_allclose(outT.cpu().numpy(), refT, rtol=1e-5, atol=1e-6 * max(np.abs(refT).max(), 1e-30))
 
 
-def test_negative_sampling_bit_exact():
+@pytest.mark.parametrize("prefilter", ["1", "0"])
+@pytest.mark.parametrize("N,E", [(200, 6000), (5000, 40000)])
+def test_negative_sampling_bit_exact(N, E, prefilter, monkeypatch):
+    """Samples bit-exact with the C oracle, with and without the edge-set bitmap prefilter (a clear bit proves "not an edge";
+    set bits still take the exact search) - N = 200 / E = 6000 is dense enough that rejections happen."""
     from causal_eeg_vae_amd import negative_sampling, CsrPair
     from oracle import c_oracle, ref_torch
-    N, E = 200, 6000  # dense enough that rejections happen
+    monkeypatch.setenv("CEEG_NEG_FILTER", prefilter)
     src, dst = _rand_graph(N, E, 5, loops=False)
     ei = torch.from_numpy(np.stack([src, dst])).cuda()
     neg = negative_sampling(ei, N, 5000, seed=77)
