@@ -666,31 +666,42 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
 
 // ================================================================================================ pair lists on a quantised latent
 // recon_loss over an ARBITRARY pair list (the negatives `negative_sampling` draws afresh every step) without building a CSR pair:
-//   forward : per pair k = (i, j): v = G[code i][code j], term and c = d term / dv; two INCIDENCE records are written,
-//             (key j, (c, code i)) and (key i, (c, code j)) - row `key` of the gradient receives c * W[code];
-//   backward: ONE stable radix sort of the 2E (32-bit key, 64-bit record) incidences groups them by node (incidence order kept
-//             inside a node: a fixed summation order, no float atomics), a boundary scan gives the row pointers, and
+//   forward : per pair k = (i, j): v = G[code i][code j], term and c = d term / dv; two 64-bit INCIDENCE records are written,
+//             rec[2k] = (j, code i, c) and rec[2k+1] = (i, code j, c) - row `node` of the gradient receives c * W[code];
+//             packed as node << 42 | code << 32 | float bits of c  (code < 2^10, node <= N < 2^22);
+//   backward: ONE stable radix sort of the 2E records on their node bits only (8-byte keys, no values: order inside a node =
+//             incidence order, a fixed summation order, no float atomics), a boundary scan gives the row pointers, and
 //             dc_pair_grad_kernel sums c * W[code] from the LDS codebook slab: dz[n] (+)= gscale * sum.
-// Pairs with an id outside [0, N) are skipped (not counted, key N: sorted behind every node).
+// Pairs with an id outside [0, N) are skipped (not counted, node field N: sorted behind every node).
 namespace {
 
-unsigned dc_key_bits(int64_t N) {  // bits that hold the value N itself (the key of skipped pairs)
+constexpr int DC_PAIR_NODE_SHIFT = 42;
+constexpr int64_t DC_PAIR_MAX_N = ((int64_t)1 << (64 - DC_PAIR_NODE_SHIFT)) - 1;  // the node field also holds the value N
+
+unsigned dc_key_bits(int64_t N) {  // bits that hold the value N itself (the node field of skipped pairs)
   unsigned b = 1;
   while (((int64_t)1 << b) <= N) ++b;
   return b;
 }
-size_t dc_pair_sort_temp(size_t M, unsigned end_bit) {
+bool dc_pair_supported(int n_e, int D, int64_t N, int64_t E) {
+  return dc_supported(n_e, D) && n_e <= 1024 && N > 0 && N <= DC_PAIR_MAX_N && E >= 0 && E < ((int64_t)1 << 30);
+}
+size_t dc_pair_sort_temp(size_t M, int64_t N) {
   size_t bytes = 0;
-  uint32_t* k = nullptr;
-  uint64_t* v = nullptr;
-  if (rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, M, 0u, end_bit, (hipStream_t)0, false) != hipSuccess) return 0;
+  uint64_t* k = nullptr;
+  if (rocprim::radix_sort_keys(nullptr, bytes, k, k, M, (unsigned)DC_PAIR_NODE_SHIFT, (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), (hipStream_t)0,
+                               false) != hipSuccess)
+    return 0;
   return bytes < 256 ? 256 : bytes;
+}
+
+__device__ __forceinline__ unsigned long long dc_pair_rec(unsigned node, unsigned code, float c) {
+  return ((unsigned long long)node << DC_PAIR_NODE_SHIFT) | ((unsigned long long)code << 32) | (unsigned long long)__float_as_uint(c);
 }
 
 __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
                                                           const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int64_t N,
-                                                          int negative, uint2* __restrict__ keys, ulonglong2* __restrict__ recs,
-                                                          float* __restrict__ part) {
+                                                          int negative, ulonglong2* __restrict__ recs, float* __restrict__ part) {
   __shared__ float red[2][4];
   float acc = 0.f, cnt = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
@@ -709,11 +720,7 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
       key_i = (unsigned)ni;
       key_j = (unsigned)nj;
     }
-    if (keys) {
-      const unsigned long long cb = (unsigned long long)__float_as_uint(c);
-      keys[e] = make_uint2(key_j, key_i);
-      recs[e] = make_ulonglong2(cb | ((unsigned long long)ki << 32), cb | ((unsigned long long)kj << 32));
-    }
+    if (recs) recs[e] = make_ulonglong2(dc_pair_rec(key_j, ki, c), dc_pair_rec(key_i, kj, c));
   }
   acc = ceeg_wave_sum(acc);
   cnt = ceeg_wave_sum(cnt);
@@ -728,13 +735,13 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
   }
 }
 
-// sorted keys -> row pointers: thread p closes every row between key[p-1] and key[p] (keys >= N count as N)
-__global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint32_t* __restrict__ keys, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
+// sorted records -> row pointers: thread p closes every row between node[p-1] and node[p] (node fields >= N count as N)
+__global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint64_t* __restrict__ recs, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p > M) return;
   int64_t cur = N, prev = -1;
-  if (p < M) { const int64_t k = (int64_t)keys[p]; cur = k < N ? k : N; }
-  if (p > 0) { const int64_t k = (int64_t)keys[p - 1]; prev = k < N ? k : N; }
+  if (p < M) { const int64_t k = (int64_t)(recs[p] >> DC_PAIR_NODE_SHIFT); cur = k < N ? k : N; }
+  if (p > 0) { const int64_t k = (int64_t)(recs[p - 1] >> DC_PAIR_NODE_SHIFT); prev = k < N ? k : N; }
   for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)p;
 }
 
@@ -796,7 +803,7 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGra
       for (int base = A_lo; __any(base < A_hi); base += 16) {
         if (base != A_lo) { r = 0ull; if (base + gl < A_hi) r = a.recs[base + gl]; }
         const int nb = A_hi - base;
-        dc_batch1(lds4, gl, __uint_as_float((unsigned)(r & 0xffffffffull)), (int)(r >> 32), nb < 0 ? 0 : nb, s);
+        dc_batch1(lds4, gl, __uint_as_float((unsigned)(r & 0xffffffffull)), (int)((r >> 32) & 0x3ffull), nb < 0 ? 0 : nb, s);
       }
       if (j < cnt) {
         float* op = a.dz + (base_n + j) * a.lddz + col0;
@@ -812,7 +819,6 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGra
 }
 
 struct DcPairWs {
-  uint32_t* keys_out;
   uint64_t* recs_out;
   int32_t* rowptr;
   unsigned int* queue;
@@ -821,12 +827,11 @@ struct DcPairWs {
 };
 size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPairWs* out) {
   const size_t M = (size_t)(2 * E);
-  const size_t tb = dc_pair_sort_temp(M, dc_key_bits(N));
+  const size_t tb = dc_pair_sort_temp(M, N);
   if (tb == 0) return 0;
-  const size_t need = ceeg_ws_part(M, 4) + ceeg_ws_part(M, 8) + ceeg_ws_part((size_t)N + 1, 4) + 1024 + ceeg_align_up(tb, 256);
+  const size_t need = ceeg_ws_part(M, 8) + ceeg_ws_part((size_t)N + 1, 4) + 1024 + ceeg_align_up(tb, 256);
   if (out) {
     CeegWs a(ws, ws_bytes);
-    out->keys_out = a.take<uint32_t>(M);
     out->recs_out = a.take<uint64_t>(M);
     out->rowptr = a.take<int32_t>((size_t)N + 1);
     out->queue = a.take<unsigned int>(256);
@@ -839,19 +844,21 @@ size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPai
 
 }  // namespace
 
+extern "C" int ceeg_pair_bce_codes_supported(int n_e, int D, int64_t N, int64_t E) { return dc_pair_supported(n_e, D, N, E) ? 1 : 0; }
+
 extern "C" size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e) {
-  if (E < 0 || N <= 0 || n_e <= 0 || E >= ((int64_t)1 << 30)) return 0;
+  if (E < 0 || N <= 0 || N > DC_PAIR_MAX_N || n_e <= 0 || E >= ((int64_t)1 << 30)) return 0;
   const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
   const size_t bwd = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
   return fwd > bwd ? fwd : bwd;
 }
 
 extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
-                                       int64_t E, int64_t N, int negative, uint32_t* keys, uint64_t* recs, float* loss_sum, void* ws,
-                                       size_t ws_bytes, void* stream) {
-  if (!W || !code || !loss_sum || E < 0 || N <= 0 || (E > 0 && (!i || !j)) || ((keys == nullptr) != (recs == nullptr))) return CEEG_EINVAL;
-  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 30)) return CEEG_EUNSUPPORTED;
-  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && (!ceeg_aligned(keys, 8) || !ceeg_aligned(recs, 16)))) return CEEG_EINVAL;
+                                       int64_t E, int64_t N, int negative, uint64_t* recs, float* loss_sum, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (!W || !code || !loss_sum || E < 0 || N <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
+  if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (recs && !ceeg_aligned(recs, 16))) return CEEG_EINVAL;
   const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
   if (ws_bytes < fwd || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -862,7 +869,7 @@ extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int
   int64_t nb = (E + 255) / 256;
   nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
   hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, n_e, code, i, j, E, N, negative & 1,
-                     reinterpret_cast<uint2*>(keys), reinterpret_cast<ulonglong2*>(recs), part);
+                     reinterpret_cast<ulonglong2*>(recs), part);
   CEEG_CHECK_LAUNCH();
   float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
   hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
@@ -871,11 +878,11 @@ extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int
   return CEEG_OK;
 }
 
-extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint32_t* keys, const uint64_t* recs, int64_t E,
-                                       int64_t N, const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes,
+extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint64_t* recs, int64_t E, int64_t N,
+                                       const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes,
                                        void* stream) {
-  if (!W || !gscale || !dz || E < 0 || N <= 0 || (E > 0 && (!keys || !recs))) return CEEG_EINVAL;
-  if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 30)) return CEEG_EUNSUPPORTED;
+  if (!W || !gscale || !dz || E < 0 || N <= 0 || (E > 0 && !recs)) return CEEG_EINVAL;
+  if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) ||
       (recs && !ceeg_aligned(recs, 8)))
     return CEEG_EINVAL;
@@ -887,10 +894,11 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
   const int64_t M = 2 * E;
   if (M > 0) {
     size_t tb = w.temp_bytes;
-    if (rocprim::radix_sort_pairs(w.temp, tb, keys, w.keys_out, recs, w.recs_out, (size_t)M, 0u, dc_key_bits(N), st, false) != hipSuccess)
+    if (rocprim::radix_sort_keys(w.temp, tb, recs, w.recs_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
+                                 (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
       return CEEG_ELAUNCH;
   }
-  hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
+  hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.recs_out, M, N, w.rowptr);
   CEEG_CHECK_LAUNCH();
   if (hipMemsetAsync(w.queue, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
   DcPairGradArgs a;

@@ -535,8 +535,8 @@ class _PairBCECodes(torch.autograd.Function):
     c * W[code] from an LDS codebook slab - no CSR pair of the list, no host sync, no float atomics."""
 
     @staticmethod
-    def supported(table):
-        return _lib.lib().ceeg_decoder_codes_supported(int(table.shape[0]), int(table.shape[1])) == 1
+    def supported(table, num_nodes, num_pairs):
+        return _lib.lib().ceeg_pair_bce_codes_supported(int(table.shape[0]), int(table.shape[1]), int(num_nodes), int(num_pairs)) == 1
 
     @staticmethod
     def forward(ctx, z, edge_index, negative, table, table_idx):
@@ -548,29 +548,28 @@ class _PairBCECodes(torch.autograd.Function):
         E = i.shape[0]
         out = torch.zeros(2, dtype=torch.float32, device=z.device)
         want = ctx.needs_input_grad[0]
-        keys = torch.empty(max(2 * E, 2), dtype=torch.int32, device=z.device) if want else None
         recs = torch.empty(max(2 * E, 2), dtype=torch.int64, device=z.device) if want else None
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, W.shape[0]), z.device)
         with _lib.timed("pair_bce_fwd"):
             _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), W.shape[0], D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N,
-                                                 int(negative), _lib.ptr(keys), _lib.ptr(recs), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 int(negative), _lib.ptr(recs), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _lib.stream()), "ceeg_pair_bce_codes_fwd")
         if want:
-            ctx.save_for_backward(W, keys, recs)
+            ctx.save_for_backward(W, recs)
         ctx.shape, ctx.E = (N, D), E
         ctx.mark_non_differentiable(out[1])
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g, _gc):
-        W, keys, recs = ctx.saved_tensors
+        W, recs = ctx.saved_tensors
         L = _lib.lib()
         N, D = ctx.shape
         dz = torch.empty(N, D, dtype=torch.float32, device=W.device)
         gs = g.detach().to(torch.float32).reshape(1).contiguous()
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(ctx.E, N, W.shape[0]), W.device)
         with _lib.timed("pair_bce_bwd"):
-            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), W.shape[0], D, keys.data_ptr(), recs.data_ptr(), ctx.E, N,
+            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), W.shape[0], D, recs.data_ptr(), ctx.E, N,
                                                  gs.data_ptr(), 0, dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
                        "ceeg_pair_bce_codes_bwd")
         return dz, None, None, None, None
@@ -870,7 +869,7 @@ class VGAEVQ(nn.Module):
             else:
                 ps, pc = _EdgeBCE.apply(z_q, graph.edge_index_i32(), False, graph.dec, W, code)
                 pos = ps / pc.clamp(min=1.0)
-            if os.environ.get("CEEG_PAIR_CODES", "1") == "1" and _PairBCECodes.supported(W):
+            if os.environ.get("CEEG_PAIR_CODES", "1") == "1" and _PairBCECodes.supported(W, N, neg_edge_index.shape[1]):
                 ns, nc = _PairBCECodes.apply(z_q, neg_edge_index, True, W, code)   # no CSR of the sampled list: one sort of incidences
             else:
                 ns, nc = _EdgeBCE.apply(z_q, neg_edge_index, True, None, W, code)

@@ -288,21 +288,22 @@ int ceeg_edge_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const i
                             int64_t E, int negative, float* coef, float* loss_sum, void* ws, size_t ws_bytes, void* stream);
 /* recon_loss over an ARBITRARY pair list on a quantised latent, with its gradient, WITHOUT a CSR of the list: the path of the
  * negatives that upstream PyG `negative_sampling` draws afresh every step (GAE.recon_loss; call site scripts/run.py:93-95 of the
- * north-star step).  Shapes as ceeg_decoder_codes_supported(n_e, D).
+ * north-star step).  ceeg_pair_bce_codes_supported(n_e, D, N, E) != 0 <=> ceeg_decoder_codes_supported(n_e, D), N < 2^22 - 1
+ * and E < 2^30 (a record packs node << 42 | code << 32 | float bits of the coefficient).
  *   forward : terms and loss_sum = {sum of terms, pairs counted} as ceeg_edge_bce_codes_fwd (pairs with an id outside [0, N) are
- *             skipped); with keys / recs non-NULL it also leaves the 2E INCIDENCES of the list: keys[2k] = j_k, recs[2k] =
- *             (c_k as float bits) | (code[i_k] << 32); keys[2k+1] = i_k, recs[2k+1] = c_k | code[j_k] << 32; key N for skipped pairs
- *             (keys: uint32 [2E], 8-byte aligned; recs: uint64 [2E], 16-byte aligned);
- *   backward: one stable device radix sort of the incidences by key (order inside a node = incidence order: fixed summation
- *             order, no float atomics), then dz[n] (+)= gscale[0] * sum_{incidences of n} c * W[code] from an LDS-resident
- *             64-column codebook slab.  gscale: device float (upstream gradient / pairs counted); accumulate != 0 adds to dz. */
+ *             skipped); with recs non-NULL (uint64 [2E], 16-byte aligned) it also leaves the 2E INCIDENCES of the list:
+ *             recs[2k] = (node j_k, code[i_k], c_k), recs[2k+1] = (node i_k, code[j_k], c_k); node field N for skipped pairs;
+ *   backward: one stable device radix sort of the records on their node bits (order inside a node = incidence order: fixed
+ *             summation order, no float atomics), then dz[n] (+)= gscale[0] * sum_{incidences of n} c * W[code] from an
+ *             LDS-resident 64-column codebook slab.  gscale: device float (upstream gradient / pairs counted); accumulate != 0
+ *             adds to dz. */
+int ceeg_pair_bce_codes_supported(int n_e, int D, int64_t N, int64_t E);
 size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e);
 int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
-                            int64_t E, int64_t N, int negative, uint32_t* keys, uint64_t* recs, float* loss_sum, void* ws,
-                            size_t ws_bytes, void* stream);
-int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint32_t* keys, const uint64_t* recs, int64_t E,
-                            int64_t N, const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes,
+                            int64_t E, int64_t N, int negative, uint64_t* recs, float* loss_sum, void* ws, size_t ws_bytes,
                             void* stream);
+int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint64_t* recs, int64_t E, int64_t N,
+                            const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
 int ceeg_decoder_codes_chunk(void);
 int ceeg_decoder_codes_supported(int n_e, int D);
 size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);
