@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (configs[2], configs[3], uniform negatives, gather ceiling)")
     ap.add_argument("--negatives", default="sigma", choices=["sigma", "uniform"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="cvgae only (SURVEY.md 8(d) config 4): weak = --graphs per rank; strong = the --graphs minibatch split over the ranks")
     return ap.parse_args()
 
 
@@ -146,7 +148,12 @@ def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
     from causal_eeg_vae_amd.synth import collate_graphs, synth_event_graph, synth_features
     from causal_eeg_vae_amd.trainer import Trainer
     G, n, e, C = args.graphs, args.nodes_per_graph, args.edges_per_graph, args.cond_dim
-    eis = [synth_event_graph(n, e, seed=(1000 + rank) * 4096 + g, device=dev) for g in range(G)]
+    first = 0
+    if getattr(args, "scaling", "weak") == "strong":   # the same G graphs whatever the world size; rank r takes a contiguous share
+        first, G = rank * (G // world), G // world
+        eis = [synth_event_graph(n, e, seed=1000 * 4096 + first + g, device=dev) for g in range(G)]
+    else:
+        eis = [synth_event_graph(n, e, seed=(1000 + rank) * 4096 + g, device=dev) for g in range(G)]
     ei, batch, N = collate_graphs(eis, [n] * G)
     x = synth_features(N, args.in_dim, seed=1000 + rank, device=dev)
     gen = torch.Generator(device=dev).manual_seed(77 + rank)
@@ -281,6 +288,8 @@ def main():
                                                  f"synthetic power-law event graph {N} nodes / {E} edges per GPU"}}))
         return
 
+    if args.scaling == "strong" and (args.workload != "cvgae" or args.graphs < world):
+        raise SystemExit("--scaling strong: the cvgae workload with at least one graph per rank (the other workloads are one shard per GPU)")
     if args.workload == "cvgae":
         el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
         t = torch.tensor([el], dtype=torch.float64, device=dev)
@@ -290,9 +299,10 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
         if rank == 0:
-            print(json.dumps({"metric": "VGAE train edges/sec", "value": args.graphs * args.edges_per_graph * world / (el / args.steps), "unit": "edges/s",
+            total_graphs = (args.graphs // world) * world if args.scaling == "strong" else args.graphs * world
+            print(json.dumps({"metric": "VGAE train edges/sec", "value": total_graphs * args.edges_per_graph / (el / args.steps), "unit": "edges/s",
                               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                               "config": {"workload": wl, "parallelism": f"dp{world}"}, "loss": last_loss}))
         if world > 1:
             dist.destroy_process_group()
