@@ -603,15 +603,15 @@ def negative_sampling_raw(graph_or_pair, num_nodes, num, seed):
     L = _lib.lib()
     pair = graph_or_pair.dec if isinstance(graph_or_pair, EventGraph) else graph_or_pair
     out = torch.empty(2, max(int(num), 1), dtype=torch.int32, device=pair.device)[:, : int(num)]
-    if getattr(pair, "neg_filter", None) is None and os.environ.get("CEEG_NEG_FILTER", "1") == "1":
-        bits = int(L.ceeg_neg_filter_bits(pair.nnz))
-        filt = torch.empty((1 << bits) // 32, dtype=torch.int32, device=pair.device)
-        _lib.check(L.ceeg_neg_filter_build(pair.rowptr.data_ptr(), pair.col.data_ptr(), pair.num_nodes, bits, filt.data_ptr(), _lib.stream()),
-                   "ceeg_neg_filter_build")
-        pair.neg_filter = (filt, bits)
-    filt, bits = getattr(pair, "neg_filter", None) or (None, 0)
-    if os.environ.get("CEEG_NEG_FILTER", "1") != "1":
-        filt, bits = None, 0
+    filt, bits = None, 0
+    if os.environ.get("CEEG_NEG_FILTER", "1") == "1":   # "0": the plain search (the checker form of the tests)
+        if getattr(pair, "neg_filter", None) is None:
+            nbits = int(L.ceeg_neg_filter_bits(pair.nnz))
+            bitmap = torch.empty((1 << nbits) // 32, dtype=torch.int32, device=pair.device)
+            _lib.check(L.ceeg_neg_filter_build(pair.rowptr.data_ptr(), pair.col.data_ptr(), pair.num_nodes, nbits, bitmap.data_ptr(),
+                                               _lib.stream()), "ceeg_neg_filter_build")
+            pair.neg_filter = (bitmap, nbits)
+        filt, bits = pair.neg_filter
     _lib.check(L.ceeg_neg_sample_uniform_filtered(pair.rowptr.data_ptr(), pair.col.data_ptr(), int(num_nodes), int(num), int(seed), _lib.ptr(filt),
                                                   bits, out[0].data_ptr(), out[1].data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform_filtered")
     return out

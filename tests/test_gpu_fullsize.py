@@ -1,6 +1,7 @@
 """BASELINE.json's full sizes through size-independent properties (the oracle cannot run these in seconds):
 config 2 (1 M nodes / 16 M edges): CSR order and checksums, SpMM adjointness <A x, y> = <x, A^T y>, linearity,
-bitwise reproducibility, fused decoder determinism + gradient consistency with the four-pass form;
+bitwise reproducibility, fused decoder determinism + gradient consistency with the four-pass form, the sampled
+negatives and their pair-list loss / gradient against float64;
 config 3 (4 Mi x 512 x 256): z_q rows are codebook rows, histogram sums to B, idempotence (fp32), reproducibility."""
 import numpy as np
 import pytest
@@ -135,6 +136,58 @@ def test_config2_fused_decoder(config2):
         close(grad, grad64)
     assert 0.99 * E < n_valid <= E                          # few permuted pairs collide with edges on a sparse graph
     assert float(outs[0][0]) > 0
+
+
+def test_config2_sampled_negatives(config2, monkeypatch):
+    """The literal sampler path at full size: E pairs from ceeg_neg_sample_uniform_filtered - identical with and without the
+    bitmap prefilter, none of them an edge or a self pair, (nearly) no holes, reproducible - and the pair-list code form
+    (ceeg_pair_bce_codes_*: incidence records, one radix sort, LDS codebook slab) against float64 torch on the same pairs:
+    count exact, loss and gradient at the north-star tolerance, two runs bitwise equal."""
+    from causal_eeg_vae_amd.models import _PairBCECodes, negative_sampling_raw
+    from _parity import close
+    N, E, ei, g = config2
+    neg = negative_sampling_raw(g, N, E, 1234)
+    monkeypatch.setenv("CEEG_NEG_FILTER", "0")
+    assert torch.equal(negative_sampling_raw(g, N, E, 1234), neg)
+    monkeypatch.delenv("CEEG_NEG_FILTER")
+    assert torch.equal(negative_sampling_raw(g, N, E, 1234), neg)
+    ok = neg[0] >= 0
+    assert int(ok.sum()) >= E - 16 and bool((neg[1][ok] >= 0).all()) and bool((neg[0][~ok] == -1).all())
+    s, d = neg[0][ok].long(), neg[1][ok].long()
+    assert bool((s != d).all()) and int(s.max()) < N and int(d.max()) < N
+    rp = g.dec.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(N, device="cuda"), rp[1:] - rp[:-1])
+    key = rows * N + g.dec.col.long()                       # ascending (dst, src)
+    nkey = d * N + s
+    pos = torch.searchsorted(key, nkey).clamp(max=key.numel() - 1)
+    assert not bool((key[pos] == nkey).any())               # no sampled pair is an edge
+    assert 0.4 < float((s < N // 2).double().mean()) < 0.6  # uniform, not degree-weighted
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    W = torch.randn(512, 128, device="cuda", generator=gen) * 0.2
+    code = torch.randint(0, 512, (N,), device="cuda", generator=gen, dtype=torch.int32)
+    zq = W[code.long()]
+    outs = []
+    for _ in range(2):
+        x = zq.clone().requires_grad_(True)
+        ns, nc = _PairBCECodes.apply(x, neg, True, W, code)
+        (ns / nc).backward()
+        outs.append((ns.detach(), nc, x.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])
+    assert int(outs[0][1]) == int(ok.sum())
+    z = zq.double()
+    grad = torch.zeros_like(z)
+    loss = torch.zeros((), dtype=torch.float64, device="cuda")
+    M = s.numel()
+    for lo in range(0, M, 2_000_000):
+        si, di = s[lo:lo + 2_000_000], d[lo:lo + 2_000_000]
+        zi, zj = z[si], z[di]
+        p = torch.sigmoid((zi * zj).sum(1))
+        loss += (-torch.log(1 - p + 1e-15)).sum() / M
+        c = p * (1 - p) / (1 - p + 1e-15) / M
+        grad.index_add_(0, si, c[:, None] * zj)
+        grad.index_add_(0, di, c[:, None] * zi)
+    close(outs[0][0] / outs[0][1], loss)
+    close(outs[0][2], grad)
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
