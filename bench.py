@@ -360,7 +360,7 @@ def main():
             if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F):
                 traffic = t["traffic_bytes"]
         neg_label = ("1:1 permutation-structured negatives (sigma affine per step, pairs colliding with an edge masked)" if args.negatives == "sigma"
-                     else "1:1 uniform negatives (negative_sampling: ceeg_neg_sample_uniform per step, per-step CSR of the samples)")
+                     else "1:1 uniform negatives (negative_sampling: E pairs from ceeg_neg_sample_uniform every step, their incidences grouped by one radix sort per step)")
         line = {"metric": "VGAE train edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -38,10 +38,16 @@ def allreduce_grads_(params, world_size):
 
 
 def broadcast_params_(module, src=0):
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src)
-    for b in module.buffers():
-        dist.broadcast(b.data, src=src)
+    """Rank `src`'s parameters and buffers to every rank.  As in allreduce_grads_, only `nccl` is handed device memory:
+    under any other backend a device tensor crosses through a host copy."""
+    staged = dist.get_backend() != "nccl"
+    for t in list(module.parameters()) + list(module.buffers()):
+        if staged and t.is_cuda:
+            host = t.data.to("cpu")
+            dist.broadcast(host, src=src)
+            t.data.copy_(host)
+        else:
+            dist.broadcast(t.data, src=src)
 
 
 class Trainer:
