@@ -43,6 +43,9 @@ struct DcGradArgs {
   unsigned int* queue;
   float* part_csr;   // [chunk*2+slot][2][D]: pieces of long CSR rows       (sum 0: cp W[kc], sum 1: cn W[kc])
   float* part_t;     // [chunk*2+slot][2][D]: pieces of long transposed rows (sum 0: cp W[kr], sum 1: cn W[ksr])
+  float* coef_sum;   // [N] or NULL: summed, scaled coefficients of every node's pairs (conditional decoders)
+  float* cpart_csr;  // [chunk*2+slot][2]: (sum cp, sum cn) of the pieces of long CSR rows
+  float* cpart_t;    // [chunk*2+slot][2]: the same for long transposed rows
 };
 
 struct DcNode {  // one pipeline stage of dc_grad_rows_kernel: a node's three lists and their first batches
@@ -308,10 +311,57 @@ __device__ __forceinline__ void dc_add_pieces(const float* __restrict__ part, in
   }
 }
 
+// Coefficient sums (conditional decoders): S[n] = gp * (sum_{p in row n} cp + sum_{q in trow n} cp[tperm q])
+//                                                  + gn * (sum_{p in row sigma^-1 n} cn + sum_{q in trow n} cn[tperm q])
+// is the factor of every decoder-input column that is CONSTANT over the pairs of a node (a per-graph condition appended to the
+// latent).  dc_grad_rows_kernel<., true> adds the coefficients it walks anyway (lane l of a node's group adds entries l, l+16,
+// ... in list order, then a fixed butterfly); the pieces of long lists are summed beforehand by dc_coef_sum_long_kernel, one wave
+// per item of the graph's static piece lists, four loads in flight per lane.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void dc_coef_sum_long_kernel(DcGradArgs a, const int4* __restrict__ items, int64_t n_items) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n_items) return;
+  const int4 itv = items[i];
+  float sp = 0.f, sn = 0.f;
+  for (int p = itv.x + lane; p < itv.y; p += 256) {
+    float x[4], y[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pu = p + 64 * u;
+      x[u] = 0.f; y[u] = 0.f;
+      if (pu < itv.y) {
+        const uint2 r = *reinterpret_cast<const uint2*>(a.rec + (TRANSPOSED ? a.t_perm[pu] : pu));
+        x[u] = __uint_as_float(r.x);
+        y[u] = __uint_as_float(r.y);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { sp += x[u]; sn += y[u]; }
+  }
+  sp = ceeg_wave_sum(sp);
+  sn = ceeg_wave_sum(sn);
+  if (lane == 0) {
+    float* o = (TRANSPOSED ? a.cpart_t : a.cpart_csr) + (size_t)itv.z * 2;
+    o[0] = sp;
+    o[1] = sn;
+  }
+}
+__device__ __forceinline__ float dc_piece_sums(const float* __restrict__ part, int lo, int hi, int which) {
+  const int c_lo = lo / DC_CHUNK, c_hi = (hi - 1) / DC_CHUNK;
+  float s = 0.f;
+  for (int c = c_lo; c <= c_hi; ++c) {  // ascending position order
+    const int slot = (c == c_lo && lo != c * DC_CHUNK) ? 1 : 0;
+    s += part[((size_t)c * 2 + slot) * 2 + which];
+  }
+  return s;
+}
+
 // Persistent grid, one workgroup per CU; workgroup b sweeps slab b % nslab.  Every wave draws 64 consecutive nodes from its
 // slab's counter (integer atomics only: which wave computes a node does not change the node's result).
 // NEG = false: positives only (every cn is 0): the sigma-row list and the cn halves of the transposed list are not walked.
-template <bool NEG>
+// CSUM: the workgroups of slab 0 also write a.coef_sum.
+template <bool NEG, bool CSUM>
 __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* lds4 = reinterpret_cast<float4*>(smem);
@@ -373,16 +423,19 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       const int j = it * 4 + grp;
       uint4 ra = s0.ra, rb = s0.rb, rc = s0.rc;
       float4 s1v = make_float4(0.f, 0.f, 0.f, 0.f), s2v = s1v, s3v = s1v, s4v = s1v;
+      float cs_p = 0.f, cs_n = 0.f;  // CSUM: this lane's share of the node's coefficient sums (absent entries carry 0)
       // (1) n as destination of positives: sum_{p in row n} cp W[kc]
       for (int base = s0.A_lo; __any(base < s0.a_hi); base += 16) {
         if (base != s0.A_lo) { ra = zero4; if (base + gl < s0.a_hi) ra = a.rec[base + gl]; }
         const int nb = s0.a_hi - base;
+        if (CSUM) cs_p += __uint_as_float(ra.x);
         dc_batch1(lds4, gl, __uint_as_float(ra.x), (int)ra.w, nb < 0 ? 0 : nb, s1v);
       }
       // (3) n as negative endpoint sigma(m): sum_{p in row m} cn W[kc]
       for (int base = s0.B_lo; NEG && __any(base < s0.b_hi); base += 16) {
         if (base != s0.B_lo) { rb = zero4; if (base + gl < s0.b_hi) rb = a.rec[base + gl]; }
         const int nb = s0.b_hi - base;
+        if (CSUM) cs_n += __uint_as_float(rb.y);
         dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3v);
       }
       // (2) + (4) n as source: sum_q cp W[kr], sum_q cn W[ksr] over the transposed row
@@ -392,6 +445,7 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
           if (base + gl < s0.c_hi) rc = a.rec[a.t_perm[base + gl]];
         }
         const int nb = s0.c_hi - base;
+        if (CSUM) { cs_p += __uint_as_float(rc.x); cs_n += __uint_as_float(rc.y); }
         if (NEG) dc_batch2(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), __uint_as_float(rc.y), (int)(rc.z >> 16), nb < 0 ? 0 : nb, s2v, s4v);
         else dc_batch1(lds4, gl, __uint_as_float(rc.x), (int)(rc.z & 0xffffu), nb < 0 ? 0 : nb, s2v);
       }
@@ -400,6 +454,20 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       if (s0.C_hi != s0.c_hi) {
         dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 0, a.D, col0, s2v);
         if (NEG) dc_add_pieces(a.part_t, s0.C_lo, s0.C_hi, 1, a.D, col0, s4v);
+      }
+      if (CSUM && slab == 0) {  // block-uniform
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+          cs_p += __shfl_xor(cs_p, o, 64);
+          cs_n += __shfl_xor(cs_n, o, 64);
+        }
+        if (s0.A_hi != s0.a_hi) cs_p += dc_piece_sums(a.cpart_csr, s0.A_lo, s0.A_hi, 0);
+        if (NEG && s0.B_hi != s0.b_hi) cs_n += dc_piece_sums(a.cpart_csr, s0.B_lo, s0.B_hi, 1);
+        if (s0.C_hi != s0.c_hi) {
+          cs_p += dc_piece_sums(a.cpart_t, s0.C_lo, s0.C_hi, 0);
+          cs_n += dc_piece_sums(a.cpart_t, s0.C_lo, s0.C_hi, 1);
+        }
+        if (j < cnt && gl == 0) a.coef_sum[base_n + j] = gp * cs_p + gn * cs_n;
       }
       if (j < cnt) {
         float4 o;
@@ -450,46 +518,12 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_long_kernel(DcGradArg
   }
 }
 
-// S[n] = gp * (sum_{p in row n} cp + sum_{q in trow n} cp[tperm q]) + gn * (sum_{p in row sigma^-1 n} cn + sum_{q in trow n} cn[tperm q]):
-// the factor of every input column that is CONSTANT over the pairs of a node (a per-graph condition appended to the latent).
-// Wave w owns nodes [64 w, 64 w + 64), a 16-lane group per node; lane l adds entries l, l+16, ... in order, then a fixed butterfly.
-__global__ __launch_bounds__(256) void dc_coef_sum_kernel(DcGradArgs a, float* __restrict__ out) {
-  const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
-  const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t n0 = w * 64;
-  if (n0 >= a.N) return;
-  const float gp = a.gscale[0], gn = a.gscale[1];
-  const int64_t n = n0 + lane;
-  int alo = 0, ahi = 0, blo = 0, bhi = 0, clo = 0, chi = 0;
-  if (n < a.N) {
-    alo = a.rowptr[n]; ahi = a.rowptr[n + 1];
-    const int64_t m = dc_sigma_inv(n, a.sig_ainv, a.sig_b, a.sig_mod);
-    blo = a.rowptr[m]; bhi = a.rowptr[m + 1];
-    clo = a.t_rowptr[n]; chi = a.t_rowptr[n + 1];
-  }
-  const int cnt = a.N - n0 < 64 ? (int)(a.N - n0) : 64;
-  for (int it = 0; it * 4 < cnt; ++it) {
-    const int j = it * 4 + grp;
-    const int A_lo = __shfl(alo, j, 64), A_hi = __shfl(ahi, j, 64), B_lo = __shfl(blo, j, 64), B_hi = __shfl(bhi, j, 64);
-    const int C_lo = __shfl(clo, j, 64), C_hi = __shfl(chi, j, 64);
-    float sp = 0.f, sn = 0.f;
-    for (int p = A_lo + gl; p < A_hi; p += 16) sp += __uint_as_float(a.rec[p].x);
-    for (int p = B_lo + gl; p < B_hi; p += 16) sn += __uint_as_float(a.rec[p].y);
-    for (int q = C_lo + gl; q < C_hi; q += 16) {
-      const uint4 r = a.rec[a.t_perm[q]];
-      sp += __uint_as_float(r.x);
-      sn += __uint_as_float(r.y);
-    }
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      sp += __shfl_xor(sp, o, 64);
-      sn += __shfl_xor(sn, o, 64);
-    }
-    if (gl == 0 && j < cnt) out[n0 + j] = gp * sp + gn * sn;
-  }
-}
-
 bool dc_supported(int n_e, int D) { return n_e >= 1 && n_e <= DC_MAX_K && D >= DC_CW && D <= 256 && (D % DC_CW) == 0; }
+size_t dc_cpart_bytes(int64_t nnz, int64_t n_items) {  // scalar (sum cp, sum cn) per piece slot
+  if (n_items <= 0) return 0;
+  const size_t nchunk = (size_t)((nnz + DC_CHUNK - 1) / DC_CHUNK);
+  return ceeg_ws_part((nchunk + 1) * 2 * 2, 4);
+}
 size_t dc_part_bytes(int64_t nnz, int D, int64_t n_items) {
   if (n_items <= 0) return 0;
   const size_t nchunk = (size_t)((nnz + DC_CHUNK - 1) / DC_CHUNK);
@@ -504,7 +538,7 @@ extern "C" int ceeg_decoder_codes_supported(int n_e, int D) { return dc_supporte
 extern "C" size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong) {
   if (N <= 0 || nnz < 0 || !dc_supported(n_e, D) || n_long < 0 || n_tlong < 0) return 0;
   const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part(((size_t)((N + 63) / 64) + (size_t)n_long) * 3, 4);
-  const size_t bwd = 1024 + dc_part_bytes(nnz, D, n_long) + dc_part_bytes(nnz, D, n_tlong);
+  const size_t bwd = 1024 + dc_part_bytes(nnz, D, n_long) + dc_part_bytes(nnz, D, n_tlong) + dc_cpart_bytes(nnz, n_long) + dc_cpart_bytes(nnz, n_tlong);
   return fwd > bwd ? fwd : bwd;
 }
 
@@ -634,6 +668,9 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
   a.queue = static_cast<unsigned int*>(ws);
   a.part_csr = reinterpret_cast<float*>(static_cast<char*>(ws) + 1024);
   a.part_t = reinterpret_cast<float*>(static_cast<char*>(ws) + 1024 + dc_part_bytes(nnz, D, n_long));
+  a.cpart_csr = reinterpret_cast<float*>(reinterpret_cast<char*>(a.part_t) + dc_part_bytes(nnz, D, n_tlong));
+  a.cpart_t = reinterpret_cast<float*>(reinterpret_cast<char*>(a.cpart_csr) + dc_cpart_bytes(nnz, n_long));
+  a.coef_sum = coef_sum;
   if (hipMemsetAsync(ws, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
   const int nslab = D / DC_CW;
   const size_t lds = (size_t)n_e * DC_CW * 4;
@@ -654,13 +691,24 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
                        reinterpret_cast<const int4*>(t_long_items), n_tlong);
     CEEG_CHECK_LAUNCH();
   }
-  if (no_neg) hipLaunchKernelGGL(dc_grad_rows_kernel<false>, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
-  else hipLaunchKernelGGL(dc_grad_rows_kernel<true>, dim3(grid_for(N)), dim3(DC_GRAD_THREADS), lds, st, a);
-  CEEG_CHECK_LAUNCH();
-  if (coef_sum) {
-    hipLaunchKernelGGL(dc_coef_sum_kernel, dim3((unsigned)(((N + 63) / 64 + 3) / 4)), dim3(256), 0, st, a, coef_sum);
-    CEEG_CHECK_LAUNCH();
+  if (coef_sum) {  // piece sums of the long lists first: dc_grad_rows_kernel adds them
+    if (n_long > 0) {
+      hipLaunchKernelGGL(dc_coef_sum_long_kernel<false>, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, a,
+                         reinterpret_cast<const int4*>(long_items), n_long);
+      CEEG_CHECK_LAUNCH();
+    }
+    if (n_tlong > 0) {
+      hipLaunchKernelGGL(dc_coef_sum_long_kernel<true>, dim3((unsigned)((n_tlong + 3) / 4)), dim3(256), 0, st, a,
+                         reinterpret_cast<const int4*>(t_long_items), n_tlong);
+      CEEG_CHECK_LAUNCH();
+    }
   }
+  const dim3 grid(grid_for(N)), block(DC_GRAD_THREADS);
+  if (no_neg && coef_sum) hipLaunchKernelGGL((dc_grad_rows_kernel<false, true>), grid, block, lds, st, a);
+  else if (no_neg) hipLaunchKernelGGL((dc_grad_rows_kernel<false, false>), grid, block, lds, st, a);
+  else if (coef_sum) hipLaunchKernelGGL((dc_grad_rows_kernel<true, true>), grid, block, lds, st, a);
+  else hipLaunchKernelGGL((dc_grad_rows_kernel<true, false>), grid, block, lds, st, a);
+  CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
 

@@ -736,17 +736,21 @@ def test_head_bias_gradient_when_the_encoder_output_feeds_a_second_loss():
     grads_close(model, ref)
 
 
-def test_decoder_code_form_with_condition_columns():
+@pytest.mark.parametrize("flip", [False, True])
+def test_decoder_code_form_with_condition_columns(flip):
     """cat((z_q, c[batch])) decoded (a) in code form with |c_graph|^2 as the row addend and coef_sum * c as the condition's
-    gradient, (b) as the concatenated matrix through the row-gather kernels: same loss, count, gradients."""
+    gradient, (b) as the concatenated matrix through the row-gather kernels: same loss, count, gradients.  Node 0 of every
+    graph is a hub with more than 256 out-edges (flip: in-edges), so the coefficient sums take their long-list phase for the
+    transposed list (flip: for the row and sigma-row lists)."""
     from causal_eeg_vae_amd import EventGraph, sigma_params
     from causal_eeg_vae_amd.models import _FusedDecoder
     import os
-    n, G, D, C, n_e = 400, 5, 128, 8, 512
-    eis = [_graph(n, 5000, 200 + g) + g * n for g in range(G)]
-    ei_np = np.concatenate(eis, axis=1)
+    n, G, D, C, n_e = 800, 4, 128, 8, 512
+    eis = [_graph(n, 10000, 200 + g)[::-1 if flip else 1] + g * n for g in range(G)]
+    ei_np = np.ascontiguousarray(np.concatenate(eis, axis=1))
     N = n * G
     g = EventGraph(torch.from_numpy(ei_np).cuda(), N)
+    assert (g.dec.max_row if flip else g.dec.max_trow) > 256
     a_, b_, ainv = sigma_params(n, 7, 1)
     torch.manual_seed(0)
     W = (torch.randn(n_e, D) * (1.5 / D ** 0.5)).cuda()
