@@ -407,6 +407,57 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_gather_probe_kernel(
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = acc.x;  // keeps the loads alive; practically never taken
 }
 
+// The same probe for a FEATURE-SLICED schedule: XCD x walks ALL rows but gathers only columns [x F/8, (x+1) F/8) of every
+// source row (128 bytes at F = 256), so each L2 holds an eighth of every row it caches - eight times as many distinct rows -
+// at the price of eight passes over the (col) stream.  An 8-lane group owns a row (eight rows per wave, eight gathers in
+// flight per lane).  No product kernel is built on it; the measurement decides whether one would pay.
+__global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_gather_probe_sliced_kernel(
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ X, int64_t ldx, int64_t N,
+    int Fs, int mode, int window, unsigned int* __restrict__ sink, unsigned int* __restrict__ queue) {
+  __shared__ unsigned int s_draw;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int xcd = blockIdx.x & 7;
+  const float* Xs = X + (int64_t)xcd * Fs;
+  const int fl = lane & 7, sub = lane >> 3;
+  const int foff = 4 * fl;
+  const bool fl_ok = foff < Fs;
+  unsigned int* q = queue + xcd * 32;
+  uint4 acc = make_uint4(0, 0, 0, 0);
+  for (;;) {
+    if (threadIdx.x == 0) s_draw = atomicAdd(q, (unsigned)(SPMM_WAVES * 8));
+    __syncthreads();
+    const int64_t r0 = (int64_t)s_draw;
+    __syncthreads();
+    if (r0 >= N) break;
+    const int64_t r = r0 + wave * 8 + sub;
+    int p_lo = 0, p_hi = 0;
+    if (r < N) {
+      p_lo = rowptr[r];
+      p_hi = rowptr[r + 1];
+      if (p_hi - p_lo > SPMM_CHUNK) p_hi = p_lo;  // hub rows excluded, as in the whole-row probe
+    }
+    for (int base = p_lo; __any(base < p_hi); base += 8) {
+      int my_c = -1;
+      if (base + fl < p_hi) {
+        my_c = col[base + fl];
+        const int d = my_c - (int)r;
+        const bool near = (d < 0 ? -d : d) <= window;
+        if (!((mode & 1) && near) && !((mode & 2) && !near)) my_c = -1;
+      }
+      uint4 x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int c = __shfl(my_c, (lane & ~7) + k, 64);
+        x[k] = make_uint4(0, 0, 0, 0);
+        if (c >= 0 && fl_ok) x[k] = *reinterpret_cast<const uint4*>(Xs + (int64_t)c * ldx + foff);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { acc.x ^= x[k].x; acc.y ^= x[k].y; acc.z ^= x[k].z; acc.w ^= x[k].w; }
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x9E3779B9u) sink[0] = acc.x;
+}
+
 }  // namespace
 
 extern "C" int ceeg_spmm_gather_probe(const int32_t* rowptr, const int32_t* col, const float* X, int64_t ldx, int64_t N, int64_t nnz,
@@ -420,6 +471,12 @@ extern "C" int ceeg_spmm_gather_probe(const int32_t* rowptr, const int32_t* col,
   if (hipMemsetAsync(queue, 0, SPMM_QUEUE_BYTES, st) != hipSuccess) return CEEG_ELAUNCH;
   const int lpr = lpr_for(F);
   const dim3 grid(8 * SPMM_BLOCKS_PER_XCD), block(SPMM_WAVES * 64);
+  if (mode & 4) {  // feature-sliced schedule: XCD x gathers columns [x F/8, (x+1) F/8) of every row
+    if ((F % 32) != 0) return CEEG_EUNSUPPORTED;
+    hipLaunchKernelGGL(spmm_gather_probe_sliced_kernel, grid, block, 0, st, rowptr, col, X, ldx, N, F / 8, mode, window, sink, queue);
+    CEEG_CHECK_LAUNCH();
+    return CEEG_OK;
+  }
   switch (lpr) {
     case 64: hipLaunchKernelGGL(spmm_gather_probe_kernel<64>, grid, block, 0, st, rowptr, col, X, ldx, N, F, mode, window, sink, queue); break;
     case 32: hipLaunchKernelGGL(spmm_gather_probe_kernel<32>, grid, block, 0, st, rowptr, col, X, ldx, N, F, mode, window, sink, queue); break;

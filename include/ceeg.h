@@ -161,7 +161,8 @@ int ceeg_spmm_csr_table(const int32_t* rowptr, const int32_t* col, const float* 
 /* Measurement entry (no reference counterpart; used by bench.py / scripts/spmm_probe.py, never by the model): the SpMM row
  * kernel's traversal with everything but the row gathers removed - no value stream, no FMAs, no epilogue, no output.  Its
  * time is the empirical ceiling of a whole-row gather SpMM on this graph.  mode bit 0: gather the entries with
- * |col - row| <= window, bit 1: the others (3 = all).  F % 4 == 0, F <= 256; ws: ceeg_spmm_ws_bytes(N, nnz, F) bytes. */
+ * |col - row| <= window, bit 1: the others (3 = all); bit 2: the FEATURE-SLICED schedule instead (XCD x walks all rows and
+ * gathers only columns [x F/8, (x+1) F/8) of each source row; F % 32 == 0).  F % 4 == 0, F <= 256; ws: ceeg_spmm_ws_bytes(N, nnz, F). */
 int ceeg_spmm_gather_probe(const int32_t* rowptr, const int32_t* col, const float* X, int64_t ldx, int64_t N, int64_t nnz,
                            int F, int mode, int window, void* ws, size_t ws_bytes, void* stream);
 

@@ -76,9 +76,10 @@ def main():
             print(json.dumps(dict(what="spmm", transposed=tr, nt=int(nt), ms=round(ms, 4), alg_TBps=round(alg / ms / 1e9, 3))))
     os.environ["CEEG_SPMM_NT"] = "0"
     for tr in ((False, True) if a.only in ("", "probe") else ()):
-        for mode, name in ((3, "all"), (1, "near"), (2, "far")):
+        for mode, name in ((3, "all"), (1, "near"), (2, "far"), (7, "all, feature-sliced per XCD"), (5, "near, feature-sliced per XCD"),
+                           (6, "far, feature-sliced per XCD")):
             ms = timeit(probe(tr, mode), a.reps)
-            n_rows = p.nnz if mode == 3 else (near_f if mode == 1 else p.nnz - near_f)
+            n_rows = p.nnz if (mode & 3) == 3 else (near_f if (mode & 3) == 1 else p.nnz - near_f)
             print(json.dumps(dict(what="gather_probe", transposed=tr, entries=name, ms=round(ms, 4), gathered_GB=round(n_rows * F * 4 / 1e9, 2),
                                   gather_TBps=round(n_rows * F * 4 / ms / 1e9, 2))))
 
