@@ -575,6 +575,79 @@ class _PairBCECodes(torch.autograd.Function):
         return dz, None, None, None, None
 
 
+class _UniformRecon(torch.autograd.Function):
+    """recon_loss(z_q, pos_edge_index, neg_edge_index) of the literal sampler path in ONE autograd node, code form throughout:
+    positives through ceeg_decoder_codes_fwd/_bwd with the structured negatives off (sig_a = 0), the sampled pairs through
+    ceeg_pair_bce_codes_fwd/_bwd - whose gradient is ACCUMULATED into the positives' dz (no second [N, D] tensor, no add).
+    Returns (pos_mean + neg_sum / neg_count, [pos_sum, neg_sum, neg_count])."""
+
+    @staticmethod
+    def supported(table, num_nodes, num_pairs):
+        L = _lib.lib()
+        return (L.ceeg_decoder_codes_supported(int(table.shape[0]), int(table.shape[1])) == 1
+                and L.ceeg_pair_bce_codes_supported(int(table.shape[0]), int(table.shape[1]), int(num_nodes), int(num_pairs)) == 1)
+
+    @staticmethod
+    def forward(ctx, z, graph, neg_edge_index, table, table_idx):
+        _lib.require_cuda(z, neg_edge_index)
+        L = _lib.lib()
+        N, D = z.shape
+        W, code = table.detach().contiguous(), table_idx.contiguous()
+        K = W.shape[0]
+        p = graph.dec
+        dev = z.device
+        li, lt = p.long_items(False), p.long_items(True)
+        nl = 0 if li is None else li.shape[0]
+        rec = torch.empty(max(p.nnz, 1), 4, dtype=torch.int32, device=dev)
+        psums = torch.empty(3, dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, K, D, nl, 0), dev)
+        with _lib.timed("decoder_fwd"):
+            _lib.check(L.ceeg_decoder_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz,
+                                                0, 0, N, _lib.ptr(li), nl, p.max_row, None, rec.data_ptr(), psums.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), _lib.stream()), "ceeg_decoder_codes_fwd")
+        i, j = _edge_lists_i32(neg_edge_index)
+        E = i.shape[0]
+        want = ctx.needs_input_grad[0]
+        nrec = torch.empty(max(2 * E, 2), dtype=torch.int64, device=dev) if want else None
+        nout = torch.zeros(2, dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, K), dev)
+        with _lib.timed("pair_bce_fwd"):
+            _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N, 1,
+                                                 _lib.ptr(nrec), nout.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                       "ceeg_pair_bce_codes_fwd")
+        inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=dev), 1.0 / nout[1].clamp(min=1.0)])
+        sums = torch.stack([psums[0], nout[0], nout[1]])
+        if want:
+            ctx.save_for_backward(W, rec, nrec, inv)
+        ctx.graph, ctx.items, ctx.shape, ctx.E = graph, (li, lt), (N, D), E
+        ctx.mark_non_differentiable(sums)
+        return psums[0] * inv[0] + nout[0] * inv[1], sums
+
+    @staticmethod
+    def backward(ctx, g, _gs):
+        W, rec, nrec, inv = ctx.saved_tensors
+        L = _lib.lib()
+        N, D = ctx.shape
+        K = W.shape[0]
+        p = ctx.graph.dec
+        li, lt = ctx.items
+        nl, nt = (0 if li is None else li.shape[0]), (0 if lt is None else lt.shape[0])
+        gscale = (inv * g).contiguous()                      # [g / E_pos, g / pairs counted]
+        dz = torch.empty(N, D, dtype=torch.float32, device=W.device)
+        ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, K, D, nl, nt), W.device)
+        with _lib.timed("decoder_bwd"):
+            _lib.check(L.ceeg_decoder_codes_bwd(W.data_ptr(), W.stride(0), K, D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(), p.t_perm.data_ptr(),
+                                                N, p.nnz, 0, 0, 1, N, _lib.ptr(li), nl, _lib.ptr(lt), nt, p.max_row, p.max_trow, rec.data_ptr(),
+                                                gscale.data_ptr(), dz.data_ptr(), dz.stride(0), None, ws.data_ptr(), ws.numel(), _lib.stream()),
+                       "ceeg_decoder_codes_bwd")
+        ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(ctx.E, N, K), W.device)
+        with _lib.timed("pair_bce_bwd"):
+            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), K, D, nrec.data_ptr(), ctx.E, N, gscale[1:].data_ptr(), 1,
+                                                 dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
+                       "ceeg_pair_bce_codes_bwd")
+        return dz, None, None, None, None
+
+
 class InnerProductDecoder(nn.Module):
     """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge (sigmoid=False: the raw inner product).  Inference-only: it
     carries no autograd path - training goes through VGAE.recon_loss, whose loss and gradient are fused kernels."""
@@ -861,6 +934,11 @@ class VGAEVQ(nn.Module):
             if neg_edge_index is None:
                 neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
             W, code = self.vector_quantization.embedding.weight, idx.view(-1).to(torch.int32)
+            codes_on = os.environ.get("CEEG_DEC_CODES", "1") == "1" and os.environ.get("CEEG_PAIR_CODES", "1") == "1"
+            if codes_on and graph.num_edges > 0 and _UniformRecon.supported(W, N, neg_edge_index.shape[1]):
+                rec, sums = _UniformRecon.apply(z_q, graph, neg_edge_index, W, code)   # both pair sets in code form, one dz
+                loss = rec + kl / N + vq_loss
+                return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums, neg_edge_index=neg_edge_index)
             if (os.environ.get("CEEG_DEC_CODES", "1") == "1" and graph.num_edges > 0
                     and _lib.lib().ceeg_decoder_codes_supported(int(W.shape[0]), int(W.shape[1])) == 1):
                 # positives: the CSR-ordered code-form decoder with its negatives switched off (sig_a = 0)
