@@ -946,8 +946,12 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
                                  (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
       return CEEG_ELAUNCH;
   }
-  hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.recs_out, M, N, w.rowptr);
-  CEEG_CHECK_LAUNCH();
+  if (M > 0) {
+    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.recs_out, M, N, w.rowptr);
+    CEEG_CHECK_LAUNCH();
+  } else if (hipMemsetAsync(w.rowptr, 0, ((size_t)N + 1) * 4, st) != hipSuccess) {  // the empty list: every row is empty
+    return CEEG_ELAUNCH;
+  }
   if (hipMemsetAsync(w.queue, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
   DcPairGradArgs a;
   a.W = W; a.ldw = ldw; a.K = n_e; a.D = D;
