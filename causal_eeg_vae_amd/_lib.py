@@ -48,8 +48,8 @@ SIGNATURES = {
     "ceeg_decoder_fused_bwd": (_c_int, [_vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_int, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_pair_bce_codes_supported": (_c_int, [_c_int, _c_int, _c_i64, _c_i64]),
     "ceeg_pair_bce_codes_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
-    "ceeg_pair_bce_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
-    "ceeg_pair_bce_codes_bwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_int, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_pair_bce_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _vp, _vp, _c_sz, _vp]),
+    "ceeg_pair_bce_codes_bwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _c_int, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_edge_bce_codes_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_edge_bce_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_spmm_csr_table": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_sz, _vp]),

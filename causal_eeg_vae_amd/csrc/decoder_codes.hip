@@ -713,18 +713,20 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
 }
 
 // ================================================================================================ pair lists on a quantised latent
-// recon_loss over an ARBITRARY pair list (the negatives `negative_sampling` draws afresh every step) without building a CSR pair:
-//   forward : per pair k = (i, j): v = G[code i][code j], term and c = d term / dv; two 64-bit INCIDENCE records are written,
-//             rec[2k] = (j, code i, c) and rec[2k+1] = (i, code j, c) - row `node` of the gradient receives c * W[code];
-//             packed as node << 42 | code << 32 | float bits of c  (code < 2^10, node <= N < 2^22);
-//   backward: ONE stable radix sort of the 2E records on their node bits only (8-byte keys, no values: order inside a node =
-//             incidence order, a fixed summation order, no float atomics), a boundary scan gives the row pointers, and
-//             dc_pair_grad_kernel sums c * W[code] from the LDS codebook slab: dz[n] (+)= gscale * sum.
+// recon_loss over an ARBITRARY pair list (the negatives `negative_sampling` draws afresh every step) without building a CSR pair.
+// On a quantised latent a pair's term and its coefficient c = d term / dv depend only on the two CODES: v = G[code i][code j].
+//   forward : dc_pair_tables_kernel tabulates term and coefficient over the K x K code pairs (G is exactly symmetric, so are
+//             the tables); per pair k = (i, j) the loss adds T[code i][code j] and two 32-bit INCIDENCE keys are written,
+//             key[2k] = j << 10 | code i and key[2k+1] = i << 10 | code j: node `key >> 10` receives c * W[key & 1023] with
+//             c = C[code node][key & 1023]  (codes < 2^10, node <= N < 2^22);
+//   backward: ONE stable keys-only radix sort of the 2E keys on their node bits (order inside a node = incidence order: a fixed
+//             summation order, no float atomics), a boundary scan gives the row pointers, and dc_pair_grad_kernel sums
+//             c * W[code] from the LDS codebook slab, the coefficients looked up in row code[n] of C: dz[n] (+)= gscale * sum.
 // Pairs with an id outside [0, N) are skipped (not counted, node field N: sorted behind every node).
 namespace {
 
-constexpr int DC_PAIR_NODE_SHIFT = 42;
-constexpr int64_t DC_PAIR_MAX_N = ((int64_t)1 << (64 - DC_PAIR_NODE_SHIFT)) - 1;  // the node field also holds the value N
+constexpr int DC_PAIR_NODE_SHIFT = 10;
+constexpr int64_t DC_PAIR_MAX_N = ((int64_t)1 << (32 - DC_PAIR_NODE_SHIFT)) - 1;  // the node field also holds the value N
 
 unsigned dc_key_bits(int64_t N) {  // bits that hold the value N itself (the node field of skipped pairs)
   unsigned b = 1;
@@ -732,43 +734,46 @@ unsigned dc_key_bits(int64_t N) {  // bits that hold the value N itself (the nod
   return b;
 }
 bool dc_pair_supported(int n_e, int D, int64_t N, int64_t E) {
-  return dc_supported(n_e, D) && n_e <= 1024 && N > 0 && N <= DC_PAIR_MAX_N && E >= 0 && E < ((int64_t)1 << 30);
+  return dc_supported(n_e, D) && n_e <= (1 << DC_PAIR_NODE_SHIFT) && N > 0 && N <= DC_PAIR_MAX_N && E >= 0 && E < ((int64_t)1 << 30);
 }
 size_t dc_pair_sort_temp(size_t M, int64_t N) {
   size_t bytes = 0;
-  uint64_t* k = nullptr;
+  uint32_t* k = nullptr;
   if (rocprim::radix_sort_keys(nullptr, bytes, k, k, M, (unsigned)DC_PAIR_NODE_SHIFT, (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), (hipStream_t)0,
                                false) != hipSuccess)
     return 0;
   return bytes < 256 ? 256 : bytes;
 }
 
-__device__ __forceinline__ unsigned long long dc_pair_rec(unsigned node, unsigned code, float c) {
-  return ((unsigned long long)node << DC_PAIR_NODE_SHIFT) | ((unsigned long long)code << 32) | (unsigned long long)__float_as_uint(c);
+// T[a][b] = term, C[a][b] = d term / dv at v = G[a][b]
+__global__ __launch_bounds__(256) void dc_pair_tables_kernel(const float* __restrict__ G, int K, int negative, float* __restrict__ T,
+                                                             float* __restrict__ C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * K) return;
+  const float v = G[i];
+  float tp, cp, tn, cn;
+  dc_terms(v, v, tp, cp, tn, cn);
+  T[i] = negative ? tn : tp;
+  C[i] = negative ? cn : cp;
 }
 
-__global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ T, int K, const int32_t* __restrict__ code,
                                                           const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int64_t N,
-                                                          int negative, ulonglong2* __restrict__ recs, float* __restrict__ part) {
+                                                          uint2* __restrict__ keys, float* __restrict__ part) {
   __shared__ float red[2][4];
   float acc = 0.f, cnt = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
     const int ni = ei[e], nj = ej[e];
-    float c = 0.f;
     unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
     if (ni >= 0 && nj >= 0 && ni < N && nj < N) {
       ki = (unsigned)dc_clamp_code(code[ni], K);
       kj = (unsigned)dc_clamp_code(code[nj], K);
-      const float v = G[(size_t)ki * K + kj];
-      float tp, cp, tn, cn;
-      dc_terms(v, v, tp, cp, tn, cn);
-      acc += negative ? tn : tp;
-      c = negative ? cn : cp;
+      acc += T[(size_t)ki * K + kj];
       cnt += 1.0f;
       key_i = (unsigned)ni;
       key_j = (unsigned)nj;
     }
-    if (recs) recs[e] = make_ulonglong2(dc_pair_rec(key_j, ki, c), dc_pair_rec(key_i, kj, c));
+    if (keys) keys[e] = make_uint2((key_j << DC_PAIR_NODE_SHIFT) | ki, (key_i << DC_PAIR_NODE_SHIFT) | kj);
   }
   acc = ceeg_wave_sum(acc);
   cnt = ceeg_wave_sum(cnt);
@@ -783,13 +788,13 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
   }
 }
 
-// sorted records -> row pointers: thread p closes every row between node[p-1] and node[p] (node fields >= N count as N)
-__global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint64_t* __restrict__ recs, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
+// sorted keys -> row pointers: thread p closes every row between node[p-1] and node[p] (node fields >= N count as N)
+__global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint32_t* __restrict__ keys, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p > M) return;
   int64_t cur = N, prev = -1;
-  if (p < M) { const int64_t k = (int64_t)(recs[p] >> DC_PAIR_NODE_SHIFT); cur = k < N ? k : N; }
-  if (p > 0) { const int64_t k = (int64_t)(recs[p - 1] >> DC_PAIR_NODE_SHIFT); prev = k < N ? k : N; }
+  if (p < M) { const int64_t k = (int64_t)(keys[p] >> DC_PAIR_NODE_SHIFT); cur = k < N ? k : N; }
+  if (p > 0) { const int64_t k = (int64_t)(keys[p - 1] >> DC_PAIR_NODE_SHIFT); prev = k < N ? k : N; }
   for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)p;
 }
 
@@ -798,7 +803,9 @@ struct DcPairGradArgs {
   int64_t ldw;
   int K, D;
   const int32_t* rowptr;
-  const uint64_t* recs;
+  const uint32_t* keys;
+  const int32_t* code;
+  const float* C;
   const float* gscale;
   float* dz;
   int64_t lddz, N;
@@ -807,8 +814,14 @@ struct DcPairGradArgs {
 };
 
 // Persistent grid as dc_grad_rows_kernel: one workgroup per CU holds a 64-column codebook slab in LDS; a wave draws 64
-// consecutive nodes, a 16-lane group owns a node and walks its incidence list 16 records at a time (the first batch of the
-// next node is in flight while this one is summed).
+// consecutive nodes, a 16-lane group owns a node and walks its incidence list 32 keys at a time (two per lane).  Two-deep
+// software pipeline over the nodes: the keys of node t+2 are in flight while the coefficients of node t+1 are looked up
+// (row code[node] of C, L2-resident) and node t is summed.
+struct DcPairNode {
+  int lo, hi, kself;
+  unsigned k0, k1;  // keys lo + gl and lo + 16 + gl (0 = none; key 0 with coefficient 0 adds 0 * W[0])
+  float c0, c1;
+};
 __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* lds4 = reinterpret_cast<float4*>(smem);
@@ -825,33 +838,51 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGra
     const int64_t base_n = (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)dv);
     if (base_n >= a.N) break;
     const int64_t n = base_n + lane;
-    int lo = 0, hi = 0;
+    int lo = 0, hi = 0, ks = 0;
     if (n < a.N) {
       lo = a.rowptr[n];
       hi = a.rowptr[n + 1];
+      ks = dc_clamp_code(a.code[n], a.K);
     }
     const int cnt = a.N - base_n < 64 ? (int)(a.N - base_n) : 64;
-    int n_lo = __shfl(lo, grp, 64), n_hi = __shfl(hi, grp, 64);
-    unsigned long long n_rec = 0ull;
-    if (n_lo + gl < n_hi) n_rec = a.recs[n_lo + gl];
+    auto bounds = [&](int it, DcPairNode& s) {  // + the keys of the first two batches
+      const int j = (it * 4 + grp) & 63;
+      s.lo = __shfl(lo, j, 64);
+      s.hi = __shfl(hi, j, 64);
+      s.kself = __shfl(ks, j, 64);
+      if (it * 4 >= cnt) s.hi = s.lo;  // wave-uniform
+      s.k0 = 0u; s.k1 = 0u;
+      if (s.lo + gl < s.hi) s.k0 = a.keys[s.lo + gl];
+      if (s.lo + 16 + gl < s.hi) s.k1 = a.keys[s.lo + 16 + gl];
+    };
+    auto coefs = [&](DcPairNode& s) {
+      const float* row = a.C + (size_t)s.kself * a.K;
+      s.c0 = 0.f; s.c1 = 0.f;
+      if (s.lo + gl < s.hi) s.c0 = row[s.k0 & 1023u];
+      if (s.lo + 16 + gl < s.hi) s.c1 = row[s.k1 & 1023u];
+    };
+    DcPairNode s0, s1, s2;
+    bounds(0, s0);
+    bounds(1, s1);
+    coefs(s0);
     for (int it = 0; it * 4 < cnt; ++it) {
+      bounds(it + 2, s2);
+      coefs(s1);
       const int j = it * 4 + grp;
-      const int A_lo = n_lo, A_hi = n_hi;
-      unsigned long long r = n_rec;
-      {  // first batch of the next node
-        const int jn = (j + 4) & 63;
-        const bool ok = (it + 1) * 4 < cnt;  // wave-uniform
-        n_lo = __shfl(lo, jn, 64);
-        n_hi = __shfl(hi, jn, 64);
-        if (!ok) n_hi = n_lo;
-        n_rec = 0ull;
-        if (n_lo + gl < n_hi) n_rec = a.recs[n_lo + gl];
-      }
       float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int base = A_lo; __any(base < A_hi); base += 16) {
-        if (base != A_lo) { r = 0ull; if (base + gl < A_hi) r = a.recs[base + gl]; }
-        const int nb = A_hi - base;
-        dc_batch1(lds4, gl, __uint_as_float((unsigned)(r & 0xffffffffull)), (int)((r >> 32) & 0x3ffull), nb < 0 ? 0 : nb, s);
+      const int len = s0.hi - s0.lo;
+      dc_batch1(lds4, gl, s0.c0, (int)(s0.k0 & 1023u), len < 0 ? 0 : len, s);
+      dc_batch1(lds4, gl, s0.c1, (int)(s0.k1 & 1023u), len - 16 < 0 ? 0 : len - 16, s);
+      const float* row = a.C + (size_t)s0.kself * a.K;
+      for (int base = s0.lo + 32; __any(base < s0.hi); base += 16) {  // lists longer than 32: keys and coefficients fetched in place
+        unsigned k = 0u;
+        float c = 0.f;
+        if (base + gl < s0.hi) {
+          k = a.keys[base + gl];
+          c = row[k & 1023u];
+        }
+        const int nb = s0.hi - base;
+        dc_batch1(lds4, gl, c, (int)(k & 1023u), nb < 0 ? 0 : nb, s);
       }
       if (j < cnt) {
         float* op = a.dz + (base_n + j) * a.lddz + col0;
@@ -862,12 +893,14 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_pair_grad_kernel(DcPairGra
         }
         *reinterpret_cast<float4*>(op) = o;
       }
+      s0 = s1;
+      s1 = s2;
     }
   }
 }
 
 struct DcPairWs {
-  uint64_t* recs_out;
+  uint32_t* keys_out;
   int32_t* rowptr;
   unsigned int* queue;
   void* temp;
@@ -877,10 +910,10 @@ size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPai
   const size_t M = (size_t)(2 * E);
   const size_t tb = dc_pair_sort_temp(M, N);
   if (tb == 0) return 0;
-  const size_t need = ceeg_ws_part(M, 8) + ceeg_ws_part((size_t)N + 1, 4) + 1024 + ceeg_align_up(tb, 256);
+  const size_t need = ceeg_ws_part(M, 4) + ceeg_ws_part((size_t)N + 1, 4) + 1024 + ceeg_align_up(tb, 256);
   if (out) {
     CeegWs a(ws, ws_bytes);
-    out->recs_out = a.take<uint64_t>(M);
+    out->keys_out = a.take<uint32_t>(M);
     out->rowptr = a.take<int32_t>((size_t)N + 1);
     out->queue = a.take<unsigned int>(256);
     out->temp = a.take<char>(tb);
@@ -889,6 +922,9 @@ size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPai
   }
   return need;
 }
+size_t dc_pair_fwd_bytes(int n_e) {  // G, T, block partials (+ 3 floats for the finalize)
+  return 2 * ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+}
 
 }  // namespace
 
@@ -896,28 +932,30 @@ extern "C" int ceeg_pair_bce_codes_supported(int n_e, int D, int64_t N, int64_t 
 
 extern "C" size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e) {
   if (E < 0 || N <= 0 || N > DC_PAIR_MAX_N || n_e <= 0 || E >= ((int64_t)1 << 30)) return 0;
-  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+  const size_t fwd = dc_pair_fwd_bytes(n_e);
   const size_t bwd = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
   return fwd > bwd ? fwd : bwd;
 }
 
 extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
-                                       int64_t E, int64_t N, int negative, uint64_t* recs, float* loss_sum, void* ws, size_t ws_bytes,
-                                       void* stream) {
-  if (!W || !code || !loss_sum || E < 0 || N <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
+                                       int64_t E, int64_t N, int negative, uint32_t* keys, float* coef_table, float* loss_sum, void* ws,
+                                       size_t ws_bytes, void* stream) {
+  if (!W || !code || !loss_sum || !coef_table || E < 0 || N <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
   if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
-  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (recs && !ceeg_aligned(recs, 16))) return CEEG_EINVAL;
-  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
-  if (ws_bytes < fwd || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && !ceeg_aligned(keys, 8)) || !ceeg_aligned(coef_table, 4)) return CEEG_EINVAL;
+  if (ws_bytes < dc_pair_fwd_bytes(n_e) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t kk = ceeg_ws_part((size_t)n_e * n_e, 4);
   float* G = static_cast<float*>(ws);
-  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + ceeg_ws_part((size_t)n_e * n_e, 4));
+  float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + kk);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * kk);
   hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dc_pair_tables_kernel, dim3((unsigned)((n_e * n_e + 255) / 256)), dim3(256), 0, st, G, n_e, negative & 1, T, coef_table);
   CEEG_CHECK_LAUNCH();
   int64_t nb = (E + 255) / 256;
   nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
-  hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, G, n_e, code, i, j, E, N, negative & 1,
-                     reinterpret_cast<ulonglong2*>(recs), part);
+  hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, i, j, E, N, reinterpret_cast<uint2*>(keys), part);
   CEEG_CHECK_LAUNCH();
   float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
   hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
@@ -926,14 +964,12 @@ extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int
   return CEEG_OK;
 }
 
-extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint64_t* recs, int64_t E, int64_t N,
-                                       const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes,
-                                       void* stream) {
-  if (!W || !gscale || !dz || E < 0 || N <= 0 || (E > 0 && !recs)) return CEEG_EINVAL;
+extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const uint32_t* keys,
+                                       const float* coef_table, int64_t E, int64_t N, const float* gscale, int accumulate, float* dz,
+                                       int64_t lddz, void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !code || !coef_table || !gscale || !dz || E < 0 || N <= 0 || (E > 0 && !keys)) return CEEG_EINVAL;
   if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
-  if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) ||
-      (recs && !ceeg_aligned(recs, 8)))
-    return CEEG_EINVAL;
+  if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16)) return CEEG_EINVAL;
   DcPairWs w;
   const size_t need = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
   if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
@@ -942,12 +978,10 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
   const int64_t M = 2 * E;
   if (M > 0) {
     size_t tb = w.temp_bytes;
-    if (rocprim::radix_sort_keys(w.temp, tb, recs, w.recs_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
+    if (rocprim::radix_sort_keys(w.temp, tb, keys, w.keys_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
                                  (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
       return CEEG_ELAUNCH;
-  }
-  if (M > 0) {
-    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.recs_out, M, N, w.rowptr);
+    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
     CEEG_CHECK_LAUNCH();
   } else if (hipMemsetAsync(w.rowptr, 0, ((size_t)N + 1) * 4, st) != hipSuccess) {  // the empty list: every row is empty
     return CEEG_ELAUNCH;
@@ -955,7 +989,7 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
   if (hipMemsetAsync(w.queue, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
   DcPairGradArgs a;
   a.W = W; a.ldw = ldw; a.K = n_e; a.D = D;
-  a.rowptr = w.rowptr; a.recs = w.recs_out; a.gscale = gscale;
+  a.rowptr = w.rowptr; a.keys = w.keys_out; a.code = code; a.C = coef_table; a.gscale = gscale;
   a.dz = dz; a.lddz = lddz; a.N = N; a.accumulate = accumulate ? 1 : 0; a.queue = w.queue;
   const int nslab = D / DC_CW;
   int64_t per_slab = (N + (DC_GRAD_THREADS / 16) - 1) / (DC_GRAD_THREADS / 16);

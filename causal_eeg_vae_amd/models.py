@@ -548,28 +548,29 @@ class _PairBCECodes(torch.autograd.Function):
         E = i.shape[0]
         out = torch.zeros(2, dtype=torch.float32, device=z.device)
         want = ctx.needs_input_grad[0]
-        recs = torch.empty(max(2 * E, 2), dtype=torch.int64, device=z.device) if want else None
+        keys = torch.empty(max(2 * E, 2), dtype=torch.int32, device=z.device) if want else None
+        ctab = torch.empty(W.shape[0] * W.shape[0], dtype=torch.float32, device=z.device)
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, W.shape[0]), z.device)
         with _lib.timed("pair_bce_fwd"):
             _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), W.shape[0], D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N,
-                                                 int(negative), _lib.ptr(recs), out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 int(negative), _lib.ptr(keys), ctab.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _lib.stream()), "ceeg_pair_bce_codes_fwd")
         if want:
-            ctx.save_for_backward(W, recs)
+            ctx.save_for_backward(W, keys, ctab, code)
         ctx.shape, ctx.E = (N, D), E
         ctx.mark_non_differentiable(out[1])
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g, _gc):
-        W, recs = ctx.saved_tensors
+        W, keys, ctab, code = ctx.saved_tensors
         L = _lib.lib()
         N, D = ctx.shape
         dz = torch.empty(N, D, dtype=torch.float32, device=W.device)
         gs = g.detach().to(torch.float32).reshape(1).contiguous()
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(ctx.E, N, W.shape[0]), W.device)
         with _lib.timed("pair_bce_bwd"):
-            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), W.shape[0], D, recs.data_ptr(), ctx.E, N,
+            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), W.shape[0], D, code.data_ptr(), keys.data_ptr(), ctab.data_ptr(), ctx.E, N,
                                                  gs.data_ptr(), 0, dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
                        "ceeg_pair_bce_codes_bwd")
         return dz, None, None, None, None
@@ -608,24 +609,25 @@ class _UniformRecon(torch.autograd.Function):
         i, j = _edge_lists_i32(neg_edge_index)
         E = i.shape[0]
         want = ctx.needs_input_grad[0]
-        nrec = torch.empty(max(2 * E, 2), dtype=torch.int64, device=dev) if want else None
+        nkeys = torch.empty(max(2 * E, 2), dtype=torch.int32, device=dev) if want else None
+        ctab = torch.empty(K * K, dtype=torch.float32, device=dev)
         nout = torch.zeros(2, dtype=torch.float32, device=dev)
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, K), dev)
         with _lib.timed("pair_bce_fwd"):
             _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N, 1,
-                                                 _lib.ptr(nrec), nout.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                                                 _lib.ptr(nkeys), ctab.data_ptr(), nout.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
                        "ceeg_pair_bce_codes_fwd")
         inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=dev), 1.0 / nout[1].clamp(min=1.0)])
         sums = torch.stack([psums[0], nout[0], nout[1]])
         if want:
-            ctx.save_for_backward(W, rec, nrec, inv)
+            ctx.save_for_backward(W, rec, nkeys, ctab, code, inv)
         ctx.graph, ctx.items, ctx.shape, ctx.E = graph, (li, lt), (N, D), E
         ctx.mark_non_differentiable(sums)
         return psums[0] * inv[0] + nout[0] * inv[1], sums
 
     @staticmethod
     def backward(ctx, g, _gs):
-        W, rec, nrec, inv = ctx.saved_tensors
+        W, rec, nkeys, ctab, code, inv = ctx.saved_tensors
         L = _lib.lib()
         N, D = ctx.shape
         K = W.shape[0]
@@ -642,7 +644,8 @@ class _UniformRecon(torch.autograd.Function):
                        "ceeg_decoder_codes_bwd")
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(ctx.E, N, K), W.device)
         with _lib.timed("pair_bce_bwd"):
-            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), K, D, nrec.data_ptr(), ctx.E, N, gscale[1:].data_ptr(), 1,
+            _lib.check(L.ceeg_pair_bce_codes_bwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), nkeys.data_ptr(), ctab.data_ptr(), ctx.E, N,
+                                                 gscale[1:].data_ptr(), 1,
                                                  dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
                        "ceeg_pair_bce_codes_bwd")
         return dz, None, None, None, None

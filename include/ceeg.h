@@ -290,21 +290,23 @@ int ceeg_edge_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const i
 /* recon_loss over an ARBITRARY pair list on a quantised latent, with its gradient, WITHOUT a CSR of the list: the path of the
  * negatives that upstream PyG `negative_sampling` draws afresh every step (GAE.recon_loss; call site scripts/run.py:93-95 of the
  * north-star step).  ceeg_pair_bce_codes_supported(n_e, D, N, E) != 0 <=> ceeg_decoder_codes_supported(n_e, D), N < 2^22 - 1
- * and E < 2^30 (a record packs node << 42 | code << 32 | float bits of the coefficient).
- *   forward : terms and loss_sum = {sum of terms, pairs counted} as ceeg_edge_bce_codes_fwd (pairs with an id outside [0, N) are
- *             skipped); with recs non-NULL (uint64 [2E], 16-byte aligned) it also leaves the 2E INCIDENCES of the list:
- *             recs[2k] = (node j_k, code[i_k], c_k), recs[2k+1] = (node i_k, code[j_k], c_k); node field N for skipped pairs;
- *   backward: one stable device radix sort of the records on their node bits (order inside a node = incidence order: fixed
- *             summation order, no float atomics), then dz[n] (+)= gscale[0] * sum_{incidences of n} c * W[code] from an
- *             LDS-resident 64-column codebook slab.  gscale: device float (upstream gradient / pairs counted); accumulate != 0
- *             adds to dz. */
+ * and E < 2^30.  A pair's term and coefficient depend only on its two codes (v = G[code i][code j], G = W W^T):
+ *   forward : coef_table (float [n_e * n_e], caller-owned, kept for the backward) receives C[a][b] = d term / dv at G[a][b];
+ *             loss_sum = {sum of terms, pairs counted} as ceeg_edge_bce_codes_fwd (pairs with an id outside [0, N) are
+ *             skipped); with keys non-NULL (uint32 [2E], 8-byte aligned) it also leaves the 2E INCIDENCES of the list:
+ *             keys[2k] = j_k << 10 | code[i_k], keys[2k+1] = i_k << 10 | code[j_k]; node field N for skipped pairs;
+ *   backward: one stable device radix sort of the keys on their node bits (order inside a node = incidence order: fixed
+ *             summation order, no float atomics), then dz[n] (+)= gscale[0] * sum_{keys of n} C[code n][key & 1023] * W[key & 1023]
+ *             from an LDS-resident 64-column codebook slab.  code: the same int32 [N] as in the forward; gscale: device float
+ *             (upstream gradient / pairs counted); accumulate != 0 adds to dz. */
 int ceeg_pair_bce_codes_supported(int n_e, int D, int64_t N, int64_t E);
 size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e);
 int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* i, const int32_t* j,
-                            int64_t E, int64_t N, int negative, uint64_t* recs, float* loss_sum, void* ws, size_t ws_bytes,
-                            void* stream);
-int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const uint64_t* recs, int64_t E, int64_t N,
-                            const float* gscale, int accumulate, float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+                            int64_t E, int64_t N, int negative, uint32_t* keys, float* coef_table, float* loss_sum, void* ws,
+                            size_t ws_bytes, void* stream);
+int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const uint32_t* keys,
+                            const float* coef_table, int64_t E, int64_t N, const float* gscale, int accumulate, float* dz,
+                            int64_t lddz, void* ws, size_t ws_bytes, void* stream);
 int ceeg_decoder_codes_chunk(void);
 int ceeg_decoder_codes_supported(int n_e, int D);
 size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);
