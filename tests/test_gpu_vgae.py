@@ -233,7 +233,7 @@ def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
 
 
 @pytest.mark.parametrize("N,E,D,n_e,negative", [(1000, 20000, 64, 100, True), (777, 5000, 128, 512, False), (64, 0, 64, 8, True),
-                                                 (130, 9000, 256, 33, True)])
+                                                 (130, 9000, 256, 33, True), (5, 40, 192, 576, False)])
 def test_pair_list_code_form_vs_fp64(N, E, D, n_e, negative):
     """ceeg_pair_bce_codes_fwd / _bwd on an arbitrary pair list (duplicates, i == j pairs, holes, ids >= N, one hub node with
     thousands of incidences, N not a multiple of 64, the empty list): sum, count and dz against fp64 torch on the same list;
