@@ -25,21 +25,41 @@ def load_event_graph_csv(nodes_csv, edges_csv):
     nodes = pd.read_csv(nodes_csv).dropna().drop_duplicates(subset="title")   # dataset.py:126-133
     edges = pd.read_csv(edges_csv)
     ids = nodes["id"].to_numpy()
-    pos = {int(v): i for i, v in enumerate(ids)}
-    first = {}
-    src, dst, cnt = [], [], []
-    for o, n in zip(edges["old_id"].to_numpy(), edges["new_id"].to_numpy()):  # dataset.py:145-156
-        if int(o) not in pos or int(n) not in pos:
-            continue
-        key = (pos[int(o)], pos[int(n)])
-        if key in first:
-            cnt[first[key]] += 1
-        else:
-            first[key] = len(src)
-            src.append(key[0]); dst.append(key[1]); cnt.append(1)
-    ei = np.array([src, dst], dtype=np.int64).reshape(2, -1)
-    return dict(edge_index=ei, entities=np.array(cnt, dtype=np.int64), num_nodes=len(ids), node_ids=ids.astype(np.int64),
-                titles=nodes["title"].tolist())
+    # CSV id -> position in the cleaned node table (-1: the node row was dropped), vectorised (dataset.py:145-156 loops in Python)
+    order = np.argsort(ids, kind="stable")
+    sid = ids[order]
+
+    def position(v):
+        v = np.asarray(v)
+        at = np.clip(np.searchsorted(sid, v), 0, max(len(sid) - 1, 0))
+        ok = (sid[at] == v) if len(sid) else np.zeros(len(v), dtype=bool)
+        return np.where(ok, order[at] if len(sid) else 0, -1)
+
+    o, n = position(edges["old_id"].to_numpy()), position(edges["new_id"].to_numpy())
+    keep = (o >= 0) & (n >= 0)
+    ei, cnt = collapse_multigraph(o[keep], n[keep], len(ids))
+    return dict(edge_index=ei, entities=cnt, num_nodes=len(ids), node_ids=ids.astype(np.int64), titles=nodes["title"].tolist())
+
+
+def collapse_multigraph(src, dst, num_nodes):
+    """Parallel (src, dst) rows -> one directed edge each, `entities` = how many rows it stood for, edges in the order of their
+    FIRST appearance (networkx's insertion order, which `predecessors` iterates: dataset.py:147-153).  numpy arrays in, numpy
+    out; torch CUDA tensors in, the same on the device (sort by pair, run lengths, re-order by first row - no host loop)."""
+    if hasattr(src, "is_cuda"):
+        import torch
+        key = src.to(torch.int64) * int(num_nodes) + dst.to(torch.int64)
+        uniq, inv, counts = torch.unique(key, return_inverse=True, return_counts=True)
+        first = torch.full((uniq.numel(),), key.numel(), dtype=torch.int64, device=key.device)
+        first.scatter_reduce_(0, inv, torch.arange(key.numel(), device=key.device), reduce="amin")
+        by_first = torch.argsort(first)
+        uniq, counts = uniq[by_first], counts[by_first]
+        return torch.stack([uniq // int(num_nodes), uniq % int(num_nodes)]), counts
+    src, dst = np.asarray(src, dtype=np.int64), np.asarray(dst, dtype=np.int64)
+    key = src * int(num_nodes) + dst
+    uniq, first, counts = np.unique(key, return_index=True, return_counts=True)
+    by_first = np.argsort(first, kind="stable")
+    uniq, counts = uniq[by_first], counts[by_first].astype(np.int64)
+    return np.stack([uniq // int(num_nodes), uniq % int(num_nodes)]).astype(np.int64).reshape(2, -1), counts
 
 
 class PredecessorIndex:

@@ -58,3 +58,23 @@ def test_device_ancestors_argument_checks():
     assert L.ceeg_top_predecessors(p, p, p, p, 4, 9, 3, p, _lib.stream()) == -2          # more predecessors than the kernel keeps
     assert L.ceeg_ancestors(p, 4, 3, None, 4, 3, 10, p, p, _lib.stream()) == -2          # cap below 39
     assert L.ceeg_ancestors(None, 4, 3, None, 4, 3, 39, p, p, _lib.stream()) == -1
+
+
+@pytest.mark.parametrize("n,rows,seed", [(50, 400, 0), (1000, 30000, 1), (7, 0, 2), (200_000, 2_000_000, 3)])
+def test_multigraph_collapse_on_device_equals_host(n, rows, seed):
+    """ingest.collapse_multigraph (dataset.py:147-153: parallel rows -> one edge with `entities` = multiplicity, edges in
+    first-appearance order) on the device against the numpy form and, for the small cases, a plain dict loop."""
+    from causal_eeg_vae_amd import ingest
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, n, rows)
+    dst = (src + rng.integers(0, 5, rows)) % n          # few distinct targets per source: many repeats
+    ei_h, cnt_h = ingest.collapse_multigraph(src, dst, n)
+    ei_d, cnt_d = ingest.collapse_multigraph(torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda(), n)
+    np.testing.assert_array_equal(ei_d.cpu().numpy(), ei_h)
+    np.testing.assert_array_equal(cnt_d.cpu().numpy(), cnt_h)
+    assert int(cnt_h.sum()) == rows and ei_h.shape == (2, len(cnt_h))
+    if rows <= 30000:
+        first = {}
+        for a, b in zip(src.tolist(), dst.tolist()):
+            first[(a, b)] = first.get((a, b), 0) + 1      # dicts keep insertion order = first appearance
+        assert list(first.keys()) == list(zip(ei_h[0].tolist(), ei_h[1].tolist())) and list(first.values()) == cnt_h.tolist()
