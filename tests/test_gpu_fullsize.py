@@ -303,3 +303,25 @@ def test_config2_gatconv_properties(config2):
 
     ref, mag = seg(src), seg(src.abs())
     assert float(((got.double() - ref).abs() / (mag + 1e-30)).max()) < 1e-5
+
+
+def test_uniform_step_above_pair_key_limit():
+    """N >= 2^22 - 1 does not fit the 32-bit incidence keys (node << 10 | code): the literal sampler step must fall back to the
+    CSR-building form and still produce a finite loss, the full pair count and gradients for every parameter."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph, _lib
+    from causal_eeg_vae_amd.synth import synth_event_graph
+    N, E, Fi, D, n_e = (1 << 22) + 1000, 8_000_000, 16, 64, 64
+    assert _lib.lib().ceeg_pair_bce_codes_supported(n_e, D, N, E) == 0
+    assert _lib.lib().ceeg_pair_bce_codes_supported(n_e, D, (1 << 22) - 2, E) == 1
+    ei = synth_event_graph(N, E, seed=5, device="cuda")
+    g = EventGraph(ei, N)
+    torch.manual_seed(0)
+    model = VGAEVQ(Fi, D, n_e, 0.25, seed=1, negatives="uniform").cuda()
+    x = torch.randn(N, Fi, device="cuda")
+    loss, aux = model(x, g, step=0)
+    loss.backward()
+    assert bool(torch.isfinite(loss)) and int(aux["dec_sums"][2]) >= E - 16
+    neg = aux["neg_edge_index"]
+    assert int(neg.max()) < N and bool((neg[0] != neg[1]).all() | (neg[0] < 0).any())
+    for name, p in model.named_parameters():
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
