@@ -237,6 +237,8 @@ def main():
     from causal_eeg_vae_amd.synth import synth_event_graph, synth_features
     from causal_eeg_vae_amd.trainer import Trainer
     _lib.check(_lib.lib().ceeg_check_device(), "ceeg_check_device")
+    tuned = _lib.enable_tuned_gemms()
+    note(f"tuned GEMM table active: {tuned}")
 
     def barrier():
         torch.cuda.synchronize()
@@ -366,7 +368,9 @@ def main():
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"GCN-VGAE+VQ train step, synthetic power-law event graph {N} nodes / {E} edges per GPU, "
                                        f"in {args.in_dim}, latent {args.latent}, {args.codes} codes, {neg_label}, Adam",
-                           "parallelism": f"dp{world}"},
+                           "parallelism": f"dp{world}",
+                           "dense_products": ("fp32 library GEMMs (hipBLASLt / rocBLAS), kernels chosen by the package's TunableOp table "
+                                              "for these shapes" if tuned else "fp32 library GEMMs (hipBLASLt), library heuristic")},
                 "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr F={F} (spmm_rows_kernel<64> + long-row pieces)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": traffic, "launches_timed": launches, "avg_launch_ms": spmm_ms,

@@ -131,6 +131,39 @@ def workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+_TUNED_GEMMS = None
+
+
+def enable_tuned_gemms(path=None):
+    """The dense products of the step stay library GEMMs (torch.mm / addmm / bmm -> hipBLASLt / rocBLAS); this selects, for
+    exactly the shapes of BASELINE's configs, the library kernel a PyTorch TunableOp sweep on an MI355X found fastest
+    (tuned_gemm_gfx950.csv next to this file: lookup only, nothing is tuned or written at run time; shapes that are not in
+    the file keep the library's own heuristic).  The file carries validators (PyTorch / HIP / hipBLASLt / rocBLAS versions,
+    gfx950): on any other stack PyTorch rejects it and the default kernels run.  CEEG_TUNED_GEMM=0 switches it off.
+    Returns True when the table is active.  Called by Trainer and bench.py; process-wide PyTorch state."""
+    global _TUNED_GEMMS
+    if _TUNED_GEMMS is not None:
+        return _TUNED_GEMMS
+    _TUNED_GEMMS = False
+    if os.environ.get("CEEG_TUNED_GEMM", "1") != "1" or not torch.cuda.is_available():
+        return False
+    try:
+        import torch.cuda.tunable as tn
+        if tn.is_enabled():          # the application manages TunableOp itself: leave it alone
+            return False
+        path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuned_gemm_gfx950.csv")
+        if not os.path.exists(path):
+            return False
+        tn.enable(True)
+        tn.tuning_enable(False)
+        _TUNED_GEMMS = bool(tn.read_file(path))
+        if not _TUNED_GEMMS:
+            tn.enable(False)
+    except Exception:               # an older / different PyTorch: the default kernels run
+        _TUNED_GEMMS = False
+    return _TUNED_GEMMS
+
+
 def require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:

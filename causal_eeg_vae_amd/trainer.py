@@ -55,6 +55,9 @@ class Trainer:
         self.model = model
         self.world_size = int(world_size)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        if any(p.is_cuda for p in self.params):
+            from . import _lib
+            _lib.enable_tuned_gemms()   # library kernels picked for the step's GEMM shapes on an MI355X (lookup table, no tuning)
         # scripts/run.py:56; on the GPU the single-kernel (fused) form of the same update: 7 launches -> 1 per step
         self.opt = torch.optim.Adam(self.params, lr=lr, fused=all(p.is_cuda for p in self.params))
         self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt)  # scripts/run.py:57 (defaults)

@@ -86,3 +86,20 @@ def test_csr_oracle_drops_and_keeps_self_loops():
     assert rp.tolist() == [0, 2, 4, 5] and col.tolist() == [0, 1, 0, 1, 2] and perm.tolist() == [-1, 3, 2, 4, 1]
     rp, col, perm = ref_torch.csr_build_np(src, dst, 3, False)
     assert rp.tolist() == [0, 1, 3, 5] and col.tolist() == [1, 0, 1, 2, 2] and perm.tolist() == [3, 2, 4, 0, 1]
+
+
+def test_tuned_gemm_table_is_well_formed_and_inert_without_a_gpu():
+    """causal_eeg_vae_amd/tuned_gemm_gfx950.csv (a TunableOp result file: validators, then one library kernel per GEMM shape
+    of BASELINE's configs) parses, names gfx950, and _lib.enable_tuned_gemms() leaves PyTorch alone when there is no GPU."""
+    import os
+    import torch
+    from causal_eeg_vae_amd import _lib
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "tuned_gemm_gfx950.csv")
+    rows = [line.strip().split(",") for line in open(path) if line.strip()]
+    validators = {r[1]: r[2] for r in rows if r[0] == "Validator"}
+    assert validators["GCN_ARCH_NAME"].startswith("gfx950") and "PT_VERSION" in validators and "HIPBLASLT_VERSION" in validators
+    entries = [r for r in rows if r[0] != "Validator"]
+    assert len(entries) >= 8 and all(len(r) == 4 and r[0].startswith("Gemm") and float(r[3]) > 0 for r in entries)
+    assert len({(r[0], r[1]) for r in entries}) == len(entries)          # one kernel per (operation, shape)
+    if not torch.cuda.is_available():
+        assert _lib.enable_tuned_gemms() is False   # (torch.cuda.tunable itself cannot even be queried without a device)
