@@ -261,8 +261,17 @@ __global__ __launch_bounds__(256) void reparam_colsum_finalize_kernel(const floa
   const int c = threadIdx.x & 15, grp = threadIdx.x >> 4;
   const int f = blockIdx.x * 16 + c;
   double s = 0.0;
-  if (f < F)
-    for (int b = grp; b < nblk; b += 16) s += (double)part[(size_t)b * F + f];
+  if (f < F) {
+    int b = grp;
+    for (; b + 16 * 7 < nblk; b += 16 * 8) {  // eight loads in flight, added in the same ascending order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(b + 16 * u) * F + f];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (double)v[u];
+    }
+    for (; b < nblk; b += 16) s += (double)part[(size_t)b * F + f];
+  }
   red[threadIdx.x] = s;
   __syncthreads();
   if (grp == 0 && f < F) {
