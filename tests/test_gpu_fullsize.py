@@ -325,3 +325,49 @@ def test_uniform_step_above_pair_key_limit():
     assert int(neg.max()) < N and bool((neg[0] != neg[1]).all() | (neg[0] < 0).any())
     for name, p in model.named_parameters():
         assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+
+
+@pytest.mark.parametrize("n_in,n_out,relu", [(128, 256, True), (256, 256, False)])
+def test_config2_dense_products_with_the_tuned_table(n_in, n_out, relu):
+    """The step's dense products at config-2 size with the tuned GEMM table active (library kernels chosen per shape,
+    causal_eeg_vae_amd/tuned_gemm_gfx950.csv): y = x W^T (+ b, ReLU), dx = g W and the split-K weight gradient against float64
+    on sampled rows / in full, at the north-star tolerance; two runs bitwise equal."""
+    from causal_eeg_vae_amd import _lib
+    from causal_eeg_vae_amd.models import _Linear
+    _lib.enable_tuned_gemms()
+    N = 1_000_000
+    gen = torch.Generator(device="cuda").manual_seed(n_in)
+    x = torch.randn(N, n_in, device="cuda", generator=gen).requires_grad_(True)
+    w = (torch.randn(n_out, n_in, device="cuda", generator=gen) / n_in ** 0.5).requires_grad_(True)
+    b = torch.randn(n_out, device="cuda", generator=gen).requires_grad_(True) if relu else None
+    g = torch.randn(N, n_out, device="cuda", generator=gen)
+    outs = []
+    for _ in range(2):
+        for t in (x, w, b):
+            if t is not None:
+                t.grad = None
+        y = _Linear.apply(x, w, b, relu)
+        y.backward(g)
+        outs.append((y.detach().clone(), x.grad.clone(), w.grad.clone()))
+    assert all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))
+    y, dx, dw = outs[0]
+    rows = torch.randint(0, N, (4096,), device="cuda", generator=gen)
+    y64 = x.detach()[rows].double() @ w.detach().double().t()
+    if relu:
+        y64 = (y64 + b.detach().double()).relu()
+    tol = lambda ref: 1e-5 * ref.abs() + 1e-6 * float(ref.abs().max())
+    assert bool(((y[rows].double() - y64).abs() <= tol(y64)).all())
+    gm = g * (y > 0) if relu else g
+    dx64 = gm[rows].double() @ w.detach().double()
+    assert bool(((dx[rows].double() - dx64).abs() <= tol(dx64)).all())
+    # the weight gradient is a 1M-deep sum of random-sign terms (|sum| ~ 10^3, sum of |terms| ~ 6 x 10^5): an fp32 accumulation
+    # cannot hold rtol 1e-5 of the (cancelled) result; the bound is stated against the sum of absolute terms instead
+    dw64 = torch.zeros(n_out, n_in, dtype=torch.float64, device="cuda")
+    dwabs = torch.zeros_like(dw64)
+    for lo in range(0, N, 125_000):
+        gs, xs = gm[lo:lo + 125_000].double(), x.detach()[lo:lo + 125_000].double()
+        dw64 += gs.t() @ xs
+        dwabs += gs.abs().t() @ xs.abs()
+    ratio = float(((dw.double() - dw64).abs() / dwabs).max())
+    print(f"dW: max |err| / sum|terms| = {ratio:.3e}")
+    assert ratio <= 1e-7
