@@ -78,3 +78,18 @@ def test_multigraph_collapse_on_device_equals_host(n, rows, seed):
         for a, b in zip(src.tolist(), dst.tolist()):
             first[(a, b)] = first.get((a, b), 0) + 1      # dicts keep insertion order = first appearance
         assert list(first.keys()) == list(zip(ei_h[0].tolist(), ei_h[1].tolist())) and list(first.values()) == cnt_h.tolist()
+
+
+@pytest.mark.parametrize("negatives", ["uniform", "sigma"])
+def test_config1_plumbing_csv_to_training(tmp_path, negatives):
+    """BASELINE configs[0] as plumbing: tables of the reference's CSV schema at its own size (97 node rows, 234 edge rows ->
+    a graph of about 90 nodes / 200 collapsed edges, `entities` weights) through ingestion, the weighted GCN normalisation and
+    20 optimizer steps of the GCN-VGAE + VQ model; the loss is finite and goes down.  Synthetic tables: the reference's own
+    CSVs are not read."""
+    from causal_eeg_vae_amd.run_csv import train_csv
+    ncsv, ecsv = _tables(tmp_path, 97, 234, 0)
+    lines = []
+    model, hist = train_csv(ncsv, ecsv, epochs=4, steps_per_epoch=5, in_dim=16, latent=8, codes=32, negatives=negatives, log=lines.append)
+    assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] < hist[0]
+    assert len(lines) == 4 and '"epoch": 3' in lines[-1]
+    assert model.vector_quantization.embedding.weight.shape == (32, 8)
