@@ -763,7 +763,7 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
   __shared__ float red[2][4];
   float acc = 0.f, cnt = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
-    const int ni = ei[e], nj = ej[e];
+    const int ni = __builtin_nontemporal_load(ei + e), nj = __builtin_nontemporal_load(ej + e);  // streams: leave L2 to code[] and T
     unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
     if (ni >= 0 && nj >= 0 && ni < N && nj < N) {
       ki = (unsigned)dc_clamp_code(code[ni], K);
@@ -773,7 +773,10 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
       key_i = (unsigned)ni;
       key_j = (unsigned)nj;
     }
-    if (keys) keys[e] = make_uint2((key_j << DC_PAIR_NODE_SHIFT) | ki, (key_i << DC_PAIR_NODE_SHIFT) | kj);
+    if (keys) {
+      __builtin_nontemporal_store((key_j << DC_PAIR_NODE_SHIFT) | ki, &keys[e].x);
+      __builtin_nontemporal_store((key_i << DC_PAIR_NODE_SHIFT) | kj, &keys[e].y);
+    }
   }
   acc = ceeg_wave_sum(acc);
   cnt = ceeg_wave_sum(cnt);
