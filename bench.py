@@ -18,6 +18,8 @@ the pure-gather ceiling of the SpMM.  --no-extras skips them.  Stand-alone: --wo
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -48,7 +50,9 @@ def parse():
     ap.add_argument("--vq-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra legs (configs[2], configs[3], uniform negatives, gather ceiling)")
-    ap.add_argument("--negatives", default="sigma", choices=["sigma", "uniform"])
+    ap.add_argument("--negatives", default="uniform", choices=["sigma", "uniform"],
+                    help="uniform = the north star's sampler (negative_sampling drawn every step, SURVEY.md 8 A6): the headline; "
+                         "sigma = permutation-structured negatives inside the fused decoder (reported as the other_negatives extra)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="cvgae only (SURVEY.md 8(d) config 4): weak = --graphs per rank; strong = the --graphs minibatch split over the ranks")
     return ap.parse_args()
@@ -205,14 +209,87 @@ def gather_ceiling_ms(graph, x_like, F):
     return out
 
 
+def launch_ranks(n, argv, script=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher around it (N > 1, WORLD_SIZE unset): start N fresh ranks with
+    torch.distributed.run as CHILD processes - this process has made no GPU call and makes none -, relay rank 0's JSON line
+    as this process's last stdout line and return the children's exit code (non-zero when any rank failed or no line came).
+    Everything else the ranks print goes to stderr."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_json = None
+    try:
+        for line in proc.stdout:
+            t = line.strip()
+            if t.startswith("{") and t.endswith("}"):
+                try:
+                    json.loads(t)
+                    line_json = t
+                    continue
+                except ValueError:
+                    pass
+            sys.stderr.write(line)
+        rc = proc.wait(timeout=timeout)
+    except BaseException:
+        proc.kill()
+        proc.wait()
+        raise
+    if rc != 0:
+        print(f"bench.py: the {n}-rank job exited with code {rc}", file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    if line_json is None:
+        print("bench.py: the ranks finished without printing a result line", file=sys.stderr)
+        return 4
+    print(line_json, flush=True)
+    return 0
+
+
+def rank_report(el, dev, world, backend):
+    """What the process group saw, so an N-rank record checks itself: ranks, backend, the device every rank ran on and the
+    per-rank time of the timed region.  Returns (max el over ranks, dict) on every rank."""
+    idx = dev.index if dev.index is not None else 0
+    if world == 1:
+        return el, {"ranks": 1, "backend": None, "devices": [idx]}
+    t = torch.tensor([el, float(idx)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    els = [float(o[0]) for o in out]
+    return max(els), {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "devices": sorted({int(o[1]) for o in out}),
+                      "devices_per_rank": [int(o[1]) for o in out],
+                      "rank_ms_per_step": {"min": None, "max": None, "_els": els}}
+
+
+def _finish_report(rep, steps):
+    r = rep.get("rank_ms_per_step")
+    if r:
+        els = r.pop("_els")
+        r["min"], r["max"] = min(els) / steps * 1e3, max(els) / steps * 1e3
+    return rep
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # the driver's command form is `python bench.py --gpus N ...`: become the launcher (no GPU call has been made)
+        if torch.cuda.device_count() < args.gpus and os.environ.get("CEEG_SHARE_GPU") != "1":
+            print(f"bench.py: --gpus {args.gpus} but {torch.cuda.device_count()} GPU(s) visible "
+                  "(CEEG_SHARE_GPU=1 CEEG_DIST_BACKEND=gloo rehearses the multi-process path on fewer)", file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
         sys.exit(2)
     # one rank per GPU; CEEG_DIST_BACKEND=gloo + CEEG_SHARE_GPU=1 is the one-GPU rehearsal of the multi-process path
     backend = os.environ.get("CEEG_DIST_BACKEND", "nccl")
@@ -294,18 +371,15 @@ def main():
         raise SystemExit("--scaling strong: the cvgae workload with at least one graph per rank (the other workloads are one shard per GPU)")
     if args.workload == "cvgae":
         el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        if world > 1:
-            if backend != "nccl":
-                t = t.cpu()
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+        el, rep = rank_report(el, dev, world, backend)
         if rank == 0:
             total_graphs = (args.graphs // world) * world if args.scaling == "strong" else args.graphs * world
-            print(json.dumps({"metric": "VGAE train edges/sec", "value": total_graphs * args.edges_per_graph / (el / args.steps), "unit": "edges/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
-                              "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": wl, "parallelism": f"dp{world}"}, "loss": last_loss}))
+            line = {"metric": "VGAE train edges/sec", "value": total_graphs * args.edges_per_graph / (el / args.steps), "unit": "edges/s",
+                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                    "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": wl, "parallelism": f"dp{world}"}, "loss": last_loss}
+            line.update(_finish_report(rep, args.steps))
+            print(json.dumps(line))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -338,12 +412,7 @@ def main():
     if not torch.isfinite(loss).item():
         print("bench.py: non-finite loss", file=sys.stderr)
         sys.exit(3)
-    t = torch.tensor([el], dtype=torch.float64, device=dev)
-    if world > 1:
-        if backend != "nccl":
-            t = t.cpu()
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    el = float(t.item())
+    el, rep = rank_report(el, dev, world, backend)
     if rank == 0:
         ms = el / args.steps * 1e3
         F = 2 * args.latent
@@ -376,38 +445,60 @@ def main():
                              "traffic": traffic, "launches_timed": launches, "avg_launch_ms": spmm_ms,
                              "algorithmic_bytes_per_launch": spmm_bytes},
                 "loss": float(loss.item())}
+        line.update(_finish_report(rep, args.steps))
         if world == 1 and not args.no_extras:
-            # Extra legs, after the headline's timed region (BASELINE metric = "edges/s; SpMM HBM GB/s; VQ MFMA util"):
-            # (1) the empirical ceiling of the roofline kernel: the same traversal with only the row gathers left
-            fwd_c, tr_c = gather_ceiling_ms(graph, x, F)
-            hub_ms = prof.get(f"spmm_F{F}", (0, 0.0))[1]
-            line["roofline"]["gather_only_ms"] = {"forward": fwd_c, "transposed_rows_le_256": tr_c}
-            line["roofline"]["launch_ms_over_gather_only_ms"] = spmm_ms / ((fwd_c + tr_c) / 2)
-            # (2) the literal sampler path of the north star on the same graph: negative_sampling per step
-            del trainer
-            model_u = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank, negatives="uniform" if args.negatives == "sigma" else "sigma").to(dev)
-            model_u.load_state_dict(model.state_dict())
-            tr_u = Trainer(model_u, lr=1e-3, world_size=1)
-            for _ in range(2):
-                tr_u.step(x, graph)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(5):
-                lu, _ = tr_u.step(x, graph)
-            torch.cuda.synchronize()
-            ms_u = (time.perf_counter() - t1) / 5 * 1e3
-            line["other_negatives"] = {"negatives": model_u.negatives, "ms_per_step": ms_u, "edges_per_s": E / (ms_u * 1e-3), "steps": 5, "loss": float(lu.item())}
-            del tr_u, model_u, graph, model
+            # Extra legs, after the headline's timed region (BASELINE metric = "edges/s; SpMM HBM GB/s; VQ MFMA util").  Each leg
+            # is on its own: a failure is recorded under the leg's key and the headline still prints.
+            def leg(key, fn):
+                try:
+                    fn()
+                except Exception as ex:  # noqa: BLE001 - recorded, never hidden
+                    line.setdefault("extras_failed", {})[key] = f"{type(ex).__name__}: {ex}"[:400]
+                    torch.cuda.empty_cache()
+
+            def leg_gather():
+                # (1) the empirical ceiling of the roofline kernel: the same traversal with only the row gathers left
+                fwd_c, tr_c = gather_ceiling_ms(graph, x, F)
+                line["roofline"]["gather_only_ms"] = {"forward": fwd_c, "transposed_rows_le_256": tr_c}
+                line["roofline"]["launch_ms_over_gather_only_ms"] = spmm_ms / ((fwd_c + tr_c) / 2)
+
+            def leg_other():
+                # (2) the same step with the other sampler (sigma = permutation-structured negatives inside the fused decoder)
+                other = "uniform" if args.negatives == "sigma" else "sigma"
+                model_u = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank, negatives=other).to(dev)
+                model_u.load_state_dict(model.state_dict())
+                tr_u = Trainer(model_u, lr=1e-3, world_size=1)
+                for _ in range(args.warmup):
+                    tr_u.step(x, graph)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    lu, _ = tr_u.step(x, graph)
+                torch.cuda.synchronize()
+                ms_u = (time.perf_counter() - t1) / args.steps * 1e3
+                line["other_negatives"] = {"negatives": other, "ms_per_step": ms_u, "edges_per_s": E / (ms_u * 1e-3), "steps": args.steps,
+                                           "loss": float(lu.item())}
+
+            leg("gather_only", leg_gather)
+            leg("other_negatives", leg_other)
+            trainer = model = graph = None
             torch.cuda.empty_cache()
             # (3) BASELINE.json configs[2] (VQ 4 Mi x 512 x 256) in both dtypes and configs[3] (64 collated graphs x 100k edges)
-            line["vq_bf16"] = run_vq(dev, "bf16", 20, 3)
-            line["vq_f32"] = run_vq(dev, "f32", 10, 2)
+            leg("vq_bf16", lambda: line.__setitem__("vq_bf16", run_vq(dev, "bf16", 20, 3)))
+            leg("vq_f32", lambda: line.__setitem__("vq_f32", run_vq(dev, "f32", 10, 2)))
             torch.cuda.empty_cache()
-            el_c, loss_c, wl_c = run_cvgae(args, dev, 20, 3)
-            line["cvgae"] = {"ms_per_step": el_c / 20 * 1e3, "edges_per_s": args.graphs * args.edges_per_graph / (el_c / 20), "steps": 20,
-                             "workload": wl_c, "loss": loss_c}
+
+            def leg_cvgae():
+                el_c, loss_c, wl_c = run_cvgae(args, dev, 20, 3)
+                line["cvgae"] = {"ms_per_step": el_c / 20 * 1e3, "edges_per_s": args.graphs * args.edges_per_graph / (el_c / 20), "steps": 20,
+                                 "workload": wl_c, "loss": loss_c}
+
+            leg("cvgae", leg_cvgae)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args)
+            except Exception as ex:  # noqa: BLE001
+                line.setdefault("extras_failed", {})["cpu_baseline"] = f"{type(ex).__name__}: {ex}"[:400]
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

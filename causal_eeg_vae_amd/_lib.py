@@ -18,6 +18,7 @@ _c_i64, _c_int, _c_f32, _c_u64, _c_sz, _vp = C.c_int64, C.c_int, C.c_float, C.c_
 # name -> (restype, argtypes); mirrors include/ceeg.h one to one
 SIGNATURES = {
     "ceeg_version": (_c_int, []),
+    "ceeg_source_hash": (C.c_char_p, []),
     "ceeg_strerror": (C.c_char_p, [_c_int]),
     "ceeg_check_device": (_c_int, []),
     "ceeg_vq_forward_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
@@ -110,6 +111,16 @@ def lib():
             fn.argtypes = args
         _lib = l
     return _lib
+
+
+def check_build_matches_sources():
+    """Raise CeegError when libceeg.so was built from other sources than the ones next to it (a stale binary): the hash the
+    Makefile baked in (ceeg_source_hash) against the hash of csrc/*.hip, csrc/*.h and include/ceeg.h in the tree."""
+    from ._srchash import source_hash
+    built, tree = lib().ceeg_source_hash().decode(), source_hash()
+    if built != tree:
+        raise CeegError(f"libceeg.so is stale: built from sources {built}, the tree holds {tree}; rebuild (make -C causal_eeg_vae_amd/csrc)")
+    return built
 
 
 def check(rc, what):

@@ -1,8 +1,11 @@
 // Library-level entry points of libceeg.so (version, error strings, device check).
 #include <string.h>
 #include "ceeg_internal.h"
+#include "build/source_hash.h"
 
 extern "C" int ceeg_version(void) { return CEEG_VERSION; }
+
+extern "C" const char* ceeg_source_hash(void) { return CEEG_SOURCE_HASH; }
 
 extern "C" const char* ceeg_strerror(int code) {
   switch (code) {

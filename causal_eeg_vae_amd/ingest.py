@@ -30,8 +30,10 @@ def load_event_graph_csv(nodes_csv, edges_csv):
     sid = ids[order]
 
     def position(v):
+        # a node id that appears on several (distinct-title) rows maps to its LAST row, as the reference's dict does
+        # (dataset.py:137: node_mapping[id] = idx overwrites): stable sort + the right-most equal entry
         v = np.asarray(v)
-        at = np.clip(np.searchsorted(sid, v), 0, max(len(sid) - 1, 0))
+        at = np.clip(np.searchsorted(sid, v, side="right") - 1, 0, max(len(sid) - 1, 0))
         ok = (sid[at] == v) if len(sid) else np.zeros(len(v), dtype=bool)
         return np.where(ok, order[at] if len(sid) else 0, -1)
 

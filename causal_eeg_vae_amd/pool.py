@@ -130,8 +130,32 @@ class GraphLayerNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(in_channels)) if affine else None
 
     def forward(self, x, batch, size=None, relu=False):
+        _lib.require_cuda(x)
+        F = x.shape[1]
+        if F % 4 or F > 2048:
+            # widths the fused kernels do not take: the same formula in torch ops on the device (float64 statistics)
+            return _graph_layernorm_torch(x, batch, size, self.weight, self.bias, self.eps, bool(relu))
         ptr = graph_ptr(batch, size)
+        if x.dtype != torch.float32:
+            # the kernels read fp32: a half / bf16 activation (autocast) is widened first and the result narrowed back
+            if not x.is_floating_point():
+                raise TypeError(f"GraphLayerNorm: floating-point input expected, got {x.dtype}")
+            return _GraphLayerNormFn.apply(x.float(), ptr, self.weight, self.bias, self.eps, bool(relu)).to(x.dtype)
         return _GraphLayerNormFn.apply(x, ptr, self.weight, self.bias, self.eps, bool(relu))
+
+
+def _graph_layernorm_torch(x, batch, size, weight, bias, eps, relu):
+    """Graph-mode LayerNorm in torch ops (device tensors; used for widths outside the fused kernels' range)."""
+    G = int(batch[-1]) + 1 if size is None else int(size)
+    xf = x.double()
+    n = torch.bincount(batch, minlength=G).clamp(min=1).double() * x.shape[1]
+    mean = torch.zeros(G, dtype=torch.float64, device=x.device).index_add_(0, batch, xf.sum(dim=1)) / n
+    xc = xf - mean.index_select(0, batch)[:, None]
+    var = torch.zeros(G, dtype=torch.float64, device=x.device).index_add_(0, batch, (xc * xc).sum(dim=1)) / n
+    out = (xc / torch.sqrt(var + eps).index_select(0, batch)[:, None]).to(x.dtype)
+    if weight is not None:
+        out = out * weight + bias
+    return torch.relu(out) if relu else out
 
 
 class _TokenPool(torch.autograd.Function):
@@ -174,5 +198,13 @@ class _TokenPool(torch.autograd.Function):
 
 
 def token_attention_pool(hidden, attn):
-    """`attn`: the nn.Linear(H, 1) of the reference's conditioners; hidden [N, T, H] -> [N, H]."""
+    """`attn`: the nn.Linear(H, 1) of the reference's conditioners; hidden [N, T, H] -> [N, H].
+    The kernels read fp32: a half / bf16 `hidden` (an autocast token encoder) is widened first and the result narrowed back
+    to its dtype - never reinterpreted."""
+    _lib.require_cuda(hidden)
+    if not hidden.is_floating_point():
+        raise TypeError(f"token_attention_pool: floating-point hidden states expected, got {hidden.dtype}")
+    if hidden.dtype != torch.float32 or attn.weight.dtype != torch.float32:
+        b = None if attn.bias is None else attn.bias.float()
+        return _TokenPool.apply(hidden.float(), attn.weight.float(), b).to(hidden.dtype)
     return _TokenPool.apply(hidden, attn.weight, attn.bias)

@@ -34,6 +34,14 @@ def test_library_exports_every_declared_symbol():
     assert b"workspace" in lib.ceeg_strerror(-3)
 
 
+def test_library_is_built_from_the_sources_in_the_tree():
+    """The hash the Makefile bakes into libceeg.so equals the hash of csrc/ + include/ceeg.h in the tree: a stale binary
+    (what the GPU box would run, since it does not build) fails here and in smoke()."""
+    from causal_eeg_vae_amd import _lib, _srchash
+    assert _lib.check_build_matches_sources() == _srchash.source_hash()
+    assert len(_srchash.source_files()) >= 12
+
+
 def test_no_cpu_fallback_in_product_path():
     from causal_eeg_vae_amd import VectorQuantizer, CeegError
     with pytest.raises(CeegError):

@@ -1,7 +1,8 @@
 """GPU: ancestor extraction for all targets at once (ceeg_top_predecessors / ceeg_ancestors /
-ceeg_ancestor_subgraph_*) against the host path of causal_eeg_vae_amd/ingest.py, which tests/test_ingest_cpu.py checks
-against a pandas + networkx restatement of scripts/dataset.py:22-46,122-156,201-225.  Synthetic tables of the reference's CSV
-schema (parity unpinned: the reference holds no expected output for this step)."""
+ceeg_ancestor_subgraph_*) against the CHECKER - the pandas + networkx restatement of scripts/dataset.py:22-46,122-156,201-225
+in tests/test_ingest_cpu.py (`_restated`, `_top`, `_anc`, nx.induced_subgraph) - fed from the restated graph itself, not
+from the product's host code; the product's host path (ingest.PredecessorIndex / ancestor_subgraph) is compared as a second
+assertion.  Synthetic tables of the reference's CSV schema (parity unpinned: the reference holds no expected output here)."""
 import numpy as np
 import pytest
 import torch
@@ -9,7 +10,52 @@ import torch
 pytestmark = pytest.mark.gpu
 pd = pytest.importorskip("pandas")
 
-from test_ingest_cpu import _tables  # noqa: E402
+nx = pytest.importorskip("networkx")
+
+from test_ingest_cpu import _anc, _restated, _tables, _top  # noqa: E402
+
+
+@pytest.mark.parametrize("n_nodes,n_rows,seed", [(97, 234, 0), (400, 3000, 1), (30, 10, 2), (1500, 20000, 3)])
+def test_device_ancestors_equal_networkx_restatement(tmp_path, n_nodes, n_rows, seed):
+    """DeviceAncestors.top / anc / count / subgraphs() against the restated reference builder directly.  The device input is
+    read off the restated networkx graph (in-edges of every node in `predecessors` order = first appearance, which is the only
+    order the tie-break depends on), so nothing of causal_eeg_vae_amd's host code sits between checker and kernels."""
+    from causal_eeg_vae_amd import ingest
+    ncsv, ecsv = _tables(tmp_path, n_nodes, n_rows, seed)
+    graph, order = _restated(ncsv, ecsv)
+    pos = {lab: i for i, lab in enumerate(order)}
+    N = len(order)
+    src, dst, ent = [], [], []
+    for lab in order:
+        for p in graph.predecessors(lab):
+            src.append(pos[p]); dst.append(pos[lab]); ent.append(graph[p][lab]["entities"])
+    ei = torch.tensor([src, dst], dtype=torch.int64).reshape(2, -1).cuda()
+    da = ingest.DeviceAncestors(ei, torch.tensor(ent, dtype=torch.int64).cuda(), N)
+    top, anc, cnt = da.top.cpu().numpy(), da.anc.cpu().numpy(), da.count.cpu().numpy()
+    sub, eptr = da.subgraphs()
+    sub, eptr = sub.cpu().numpy(), eptr.cpu().numpy()
+    assert eptr[0] == 0 and eptr[-1] == sub.shape[1]
+    n_anc = n_sub = 0
+    for lab in order:
+        v = pos[lab]
+        assert [int(x) for x in top[v] if x >= 0] == [pos[p] for p in _top(graph, lab, ingest.MAX_TOP_PREDECESSORS)]
+        a_labs = _anc(graph, lab, ingest.NUM_GENERATIONS, ingest.MAX_TOP_PREDECESSORS)
+        want = sorted(pos[p] for p in a_labs)
+        assert cnt[v] == len(want) and anc[v, : cnt[v]].tolist() == want and (anc[v, cnt[v]:] == -1).all()
+        loc = {g: i for i, g in enumerate(want)}
+        ind = nx.induced_subgraph(graph, a_labs)
+        want_edges = sorted((loc[pos[b]], loc[pos[a]]) for a, b in ind.edges())         # (target, source), local ids
+        mine = sub[:, eptr[v]: eptr[v + 1]]
+        assert list(zip(mine[1].tolist(), mine[0].tolist())) == want_edges
+        n_anc += len(want)
+        n_sub += len(want_edges)
+    if n_rows > 100:
+        assert n_anc > 0 and n_sub > 0
+    tg = torch.arange(0, N, 3, dtype=torch.int64).cuda()
+    d2 = ingest.DeviceAncestors(ei, torch.tensor(ent, dtype=torch.int64).cuda(), N, targets=tg, num_gens=2, num_predecessors=2)
+    a2, c2 = d2.anc.cpu().numpy(), d2.count.cpu().numpy()
+    for i, v in enumerate(tg.cpu().tolist()):
+        assert a2[i, : c2[i]].tolist() == sorted(pos[p] for p in _anc(graph, order[v], 2, 2))
 
 
 @pytest.mark.parametrize("n_nodes,n_rows,seed", [(97, 234, 0), (400, 3000, 1), (30, 10, 2), (3000, 40000, 3)])

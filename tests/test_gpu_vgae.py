@@ -874,3 +874,47 @@ def test_graph_conditioner_vs_oracle():
         g, w = p.grad.cpu().double(), want[name].grad.double()
         tol = 1e-5 * w.abs() + 1e-6 * float(w.abs().max()) + 1e-6 * scale
         assert bool(((g - w).abs() <= tol).all()), (name, float((g - w).abs().max()), float(w.abs().max()), scale)
+
+
+def test_pool_kernels_reduced_precision_and_odd_widths():
+    """The fp32-only kernels behind token_attention_pool / GraphLayerNorm never reinterpret other dtypes: a bf16 hidden state
+    (an autocast token encoder) or a bf16 / half activation is widened, the result comes back in the input's dtype and equals
+    the fp32 path on the same (rounded) values; integer inputs raise; widths the fused LayerNorm does not take (F % 4 != 0)
+    run the torch-op form on the device and match the fp64 restatement."""
+    from causal_eeg_vae_amd.pool import GraphLayerNorm, token_attention_pool
+    from oracle import ref_torch
+    torch.manual_seed(3)
+    attn = torch.nn.Linear(48, 1).cuda()
+    hidden = torch.randn(9, 7, 48, device="cuda")
+    for dt in (torch.bfloat16, torch.float16):
+        hb = hidden.to(dt)
+        out = token_attention_pool(hb, attn)
+        assert out.dtype == dt
+        want = token_attention_pool(hb.float(), attn)
+        assert torch.equal(out, want.to(dt))
+    with pytest.raises(TypeError):
+        token_attention_pool(torch.zeros(2, 3, 8, dtype=torch.int32, device="cuda"), attn)
+    hb = hidden.to(torch.bfloat16).requires_grad_(True)
+    token_attention_pool(hb, attn).float().sum().backward()
+    assert hb.grad is not None and hb.grad.dtype == torch.bfloat16
+
+    sizes = [5, 1, 40]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    ln = GraphLayerNorm(64).cuda()
+    x = torch.randn(sum(sizes), 64, device="cuda")
+    xb = x.to(torch.bfloat16)
+    out = ln(xb, batch.cuda(), len(sizes), relu=True)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, ln(xb.float(), batch.cuda(), len(sizes), relu=True).to(torch.bfloat16))
+    for F in (10, 7):
+        ln = GraphLayerNorm(F).cuda()
+        with torch.no_grad():
+            ln.weight.normal_(); ln.bias.normal_()
+        x = torch.randn(sum(sizes), F)
+        a = x.double().requires_grad_(True)
+        ref = ref_torch.ref_graph_layer_norm(a, batch, len(sizes), ln.weight.detach().cpu().double(), ln.bias.detach().cpu().double())
+        (ref * x.double()).sum().backward()
+        b = x.clone().cuda().requires_grad_(True)
+        out = ln(b, batch.cuda(), len(sizes))
+        (out * x.cuda()).sum().backward()
+        _close(out, ref)
+        _close(b.grad, a.grad)

@@ -93,3 +93,20 @@ def test_csv_to_graph_and_ancestors(tmp_path, n_nodes, n_rows, seed):
         assert sub.shape[1] == ind.number_of_edges() and keep == sorted(a)
     if n_rows > 100:
         assert some_anc > 0
+
+
+def test_duplicated_node_id_maps_to_its_last_row(tmp_path):
+    """dataset.py:137 `node_mapping[node_row['id']] = idx`: when an id appears on two rows (distinct titles, so both survive
+    the cleaning) the LAST row wins; edges naming that id attach there."""
+    nodes = pd.DataFrame({"title": ["a", "b", "c", "d"], "text": ["t"] * 4, "publish_date": ["2021-01-01"] * 4, "url": ["u"] * 4,
+                          "id": [7, 5, 7, 9]})
+    edges = pd.DataFrame({"old_id": [5, 7, 7], "new_id": [7, 9, 9], "entity": ["x", "y", "z"], "entity_type": "LOC", "date_diff": [1, 2, 3]})
+    npth, epth = tmp_path / "n.csv", tmp_path / "e.csv"
+    nodes.to_csv(npth, index=False)
+    edges.to_csv(epth, index=False)
+    got = ingest.load_event_graph_csv(str(npth), str(epth))
+    graph, order = _restated(str(npth), str(epth))
+    pos = {lab: i for i, lab in enumerate(order)}
+    want = {(pos[a], pos[b]): d["entities"] for a, b, d in graph.edges(data=True)}
+    have = {(int(a), int(b)): int(w) for a, b, w in zip(got["edge_index"][0], got["edge_index"][1], got["entities"])}
+    assert have == want == {(1, 2): 1, (2, 3): 2}
