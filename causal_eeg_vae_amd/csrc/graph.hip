@@ -7,6 +7,7 @@
 // header-only, compiled into this library; temporary storage comes from the caller's workspace).
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include "ceeg_internal.h"
 
 namespace {
@@ -267,6 +268,9 @@ extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int
   const size_t need = sort_layout(nnz, N, end_bit, nullptr, 0, nullptr);
   if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   if (sort_layout(nnz, N, end_bit, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  // `nnz` may be a CAPACITY (>= rowptr[N], the true count, which then never has to cross to the host): positions the rows do
+  // not cover keep the all-ones key, sort behind every entry and are ignored by the finish kernel
+  if (nnz > 0 && hipMemsetAsync(w.keys_in, 0xff, (size_t)nnz * 8, st) != hipSuccess) return CEEG_ELAUNCH;
   hipLaunchKernelGGL(csr_transpose_keys_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in);
   CEEG_CHECK_LAUNCH();
   size_t tb = w.temp_bytes;
@@ -276,6 +280,89 @@ extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int
   }
   hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((nnz + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, nnz, N, t_rowptr,
                      t_col, t_perm, (int64_t*)nullptr);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- row statistics + piece lists
+// What the host needs to know about a freshly built CSR before it can launch on it - the entry count, the longest row and the
+// piece list of the rows longer than `chunk` entries (ceeg_spmm_csr_items / ceeg_decoder_codes_* layout) - produced ON THE DEVICE
+// into one small record, so that a graph built inside a training loop (a new minibatch every step, scripts/run.py:310-326) costs
+// ONE host read instead of one per quantity.
+namespace {
+__global__ __launch_bounds__(256) void csr_piece_count_kernel(const int32_t* __restrict__ rowptr, int64_t N, int chunk,
+                                                              int32_t* __restrict__ cnt, unsigned long long* __restrict__ rec) {
+  __shared__ int red[4];
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int len = 0;
+  if (r < N) {
+    const int lo = rowptr[r], hi = rowptr[r + 1];
+    len = hi - lo;
+    cnt[r] = len > chunk ? (hi - 1) / chunk - lo / chunk + 1 : 0;
+  } else if (r == N) {
+    cnt[N] = 0;
+    rec[0] = (unsigned long long)rowptr[N];
+  }
+  int m = len;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (m > 0) atomicMax(&rec[1], (unsigned long long)m);  // integer max: order-independent
+  }
+}
+__global__ __launch_bounds__(256) void csr_piece_fill_kernel(const int32_t* __restrict__ rowptr, int64_t N, int chunk,
+                                                             const int32_t* __restrict__ off, int4* __restrict__ items, int64_t cap,
+                                                             unsigned long long* __restrict__ rec) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r == N) rec[2] = (unsigned long long)off[N];
+  if (r >= N) return;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  if (hi - lo <= chunk) return;
+  const int c_lo = lo / chunk, c_hi = (hi - 1) / chunk;
+  int64_t o = off[r];
+  for (int c = c_lo; c <= c_hi; ++c, ++o) {
+    if (o >= cap) return;  // the host sees rec[2] > cap and raises
+    const int plo = max(lo, c * chunk), phi = (int)min((int64_t)hi, ((int64_t)c + 1) * chunk);
+    const int slot = (c == c_lo && lo != c * chunk) ? 1 : 0;
+    items[o] = make_int4(plo, phi, c * 2 + slot, (int)r);
+  }
+}
+size_t piece_scan_temp(int64_t n) {
+  size_t bytes = 0;
+  int32_t* p = nullptr;
+  if (rocprim::exclusive_scan(nullptr, bytes, p, p, 0, (size_t)n, rocprim::plus<int32_t>(), (hipStream_t)0, false) != hipSuccess) return 0;
+  return bytes < 256 ? 256 : bytes;
+}
+}  // namespace
+
+extern "C" size_t ceeg_csr_long_items_ws_bytes(int64_t N) {
+  if (N <= 0) return 0;
+  return 2 * ceeg_ws_part((size_t)N + 1, 4) + ceeg_align_up(piece_scan_temp(N + 1), 256);
+}
+
+extern "C" int ceeg_csr_long_items(const int32_t* rowptr, int64_t N, int chunk, int32_t* items, int64_t items_cap, int64_t* record,
+                                   void* ws, size_t ws_bytes, void* stream) {
+  if (!rowptr || !record || N <= 0 || chunk <= 0 || items_cap < 0 || (items_cap > 0 && (!items || !ceeg_aligned(items, 16)))) return CEEG_EINVAL;
+  if (N >= ((int64_t)1 << 31) - 1) return CEEG_EUNSUPPORTED;
+  const size_t need = ceeg_csr_long_items_ws_bytes(N);
+  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CeegWs a(ws, ws_bytes);
+  int32_t* cnt = a.take<int32_t>((size_t)N + 1);
+  int32_t* off = a.take<int32_t>((size_t)N + 1);
+  size_t tb = piece_scan_temp(N + 1);
+  void* temp = a.take<char>(tb);
+  if (!a.ok) return CEEG_EWORKSPACE;
+  if (hipMemsetAsync(record, 0, 3 * sizeof(int64_t), st) != hipSuccess) return CEEG_ELAUNCH;
+  unsigned long long* rec = reinterpret_cast<unsigned long long*>(record);
+  const dim3 grid((unsigned)((N + 1 + 255) / 256));
+  hipLaunchKernelGGL(csr_piece_count_kernel, grid, dim3(256), 0, st, rowptr, N, chunk, cnt, rec);
+  CEEG_CHECK_LAUNCH();
+  if (rocprim::exclusive_scan(temp, tb, cnt, off, 0, (size_t)N + 1, rocprim::plus<int32_t>(), st, false) != hipSuccess) return CEEG_ELAUNCH;
+  hipLaunchKernelGGL(csr_piece_fill_kernel, grid, dim3(256), 0, st, rowptr, N, chunk, off, reinterpret_cast<int4*>(items), items_cap, rec);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

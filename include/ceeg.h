@@ -115,6 +115,7 @@ int ceeg_vq_backward(const void* z, const float* W, const int64_t* idx, const vo
  *     col/perm must have that capacity.
  * ceeg_csr_transpose: CSR (rows=dst) -> CSR of the transpose (rows=src), entries ordered by
  *   (src, dst, position); tperm[q] = position p in the input CSR, so values permute as val_t[q]=val[tperm[q]].
+ *   `nnz` may be an upper bound (the capacity of col / t_col / t_perm) when the true count rowptr[N] is still on the device.
  * ceeg_gcn_norm: val[p] = dinv[col[p]] * w[p] * dinv[row(p)], deg[i] = sum_{p in row i} w[p]
  *   (in-degree at the target incl. the self-loop), dinv = deg^-1/2 (0 where deg == 0).  w == NULL means
  *   all ones; else w[p] = ew[perm[p]] for real edges and 1 for added self-loops (ew: [E] fp32).
@@ -129,6 +130,17 @@ int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, i
                        void* ws, size_t ws_bytes, void* stream);
 int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew,
                   int64_t nnz, int64_t N, float* deg_inv_sqrt, float* val, void* stream);
+/* What host code must know about a freshly built CSR before it can launch on it, produced on the DEVICE in one small record so
+ * that a graph built inside the training loop (a new PyG minibatch every step, scripts/run.py:310-326) costs ONE host read:
+ *   record[0] = rowptr[N] (the entry count; ceeg_csr_transpose and ceeg_gcn_norm accept a capacity >= it as their `nnz`, the
+ *               array tails beyond it are never read), record[1] = the longest row, record[2] = number of pieces;
+ *   items     = the piece list of the rows longer than `chunk` entries in the layout of ceeg_spmm_csr_items /
+ *               ceeg_decoder_codes_*: int32 [n][4] = (lo, hi, chunk_index*2 + slot, row), rows and pieces ascending; at most
+ *               items_cap are written (3 * nnz / chunk always suffices; record[2] > items_cap tells the host it did not).
+ * record: int64 [3] on the device.  No counterpart in the reference (PyG's collation keeps its slice_dict on the host). */
+size_t ceeg_csr_long_items_ws_bytes(int64_t N);
+int ceeg_csr_long_items(const int32_t* rowptr, int64_t N, int chunk, int32_t* items, int64_t items_cap, int64_t* record,
+                        void* ws, size_t ws_bytes, void* stream);
 
 /* Deterministic CSR segmented SpMM (the GCNConv aggregation and every transposed/backward pass):
  *   out[i,:] = act( sum_{p=rowptr[i]}^{rowptr[i+1]-1} v(p) * X[col[p],:]  + bias )      i in [0,N)
