@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--negatives", default="uniform", choices=["sigma", "uniform"],
                     help="uniform = the north star's sampler (negative_sampling drawn every step, SURVEY.md 8 A6): the headline; "
                          "sigma = permutation-structured negatives inside the fused decoder (reported as the other_negatives extra)")
+    ap.add_argument("--fresh-batches", type=int, default=0,
+                    help="cvgae only: K > 0 = a minibatch stream - K resident minibatches visited round-robin, collation and graph construction "
+                         "inside the timed region of every step (scripts/run.py:310-326)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="cvgae only (SURVEY.md 8(d) config 4): weak = --graphs per rank; strong = the --graphs minibatch split over the ranks")
     return ap.parse_args()
@@ -180,6 +183,57 @@ def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
     el = time.perf_counter() - t0
     return el, float(loss.item()), (f"conditional GCN-VGAE+VQ train step, {G} collated graphs x {e} edges x {n} nodes per GPU, in {args.in_dim}+{C}, "
                                     f"latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 permutation-structured negatives, Adam")
+
+
+def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=None):
+    """configs[3] as the minibatch STREAM the reference's loader produces (scripts/run.py:310-326: a new batch every step):
+    `fresh` pre-generated minibatches (per-graph edge lists, features and conditions resident in HBM) are visited round-robin and
+    EVERYTHING per-batch happens inside the timed region - device collation (CollatedBatch), both CSR pairs with their
+    transposes, gcn_norm, piece lists, the layout check (one host read for all of it) - followed by the optimizer step.
+    Returns (seconds, graph_build_ms measured with HIP events around the construction, last loss, label)."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ
+    from causal_eeg_vae_amd.collate import CollatedBatch
+    from causal_eeg_vae_amd.synth import synth_event_graph, synth_features
+    from causal_eeg_vae_amd.trainer import Trainer
+    G, n, e, C = args.graphs, args.nodes_per_graph, args.edges_per_graph, args.cond_dim
+    batches = []
+    for k in range(fresh):
+        eis = [synth_event_graph(n, e, seed=((1000 + rank) * 64 + k) * 4096 + g, device=dev) for g in range(G)]
+        gen = torch.Generator(device=dev).manual_seed(77 + rank + 1000 * k)
+        batches.append((eis, synth_features(G * n, args.in_dim, seed=1000 + rank + 31 * k, device=dev), torch.randn(G, C, generator=gen, device=dev)))
+    torch.manual_seed(0)
+    model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
+    with torch.no_grad():
+        model.vector_quantization.embedding.weight.normal_(0, 0.1)
+    trainer = Trainer(model, lr=1e-3, world_size=world)
+    sync = barrier or torch.cuda.synchronize
+    sizes = [n] * G
+    evs = []
+
+    def one(k, timed):
+        eis, x, cond = batches[k % fresh]
+        if timed:
+            s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+        cb = CollatedBatch(eis, sizes)
+        graph = cb.event_graph(with_dec=True)
+        if timed:
+            t.record()
+            evs.append((s, t))
+        return trainer.step(x, graph, cb.batch, cond, nodes_per_graph=n)
+
+    for k in range(warmup):
+        one(k, False)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        loss, aux = one(warmup + k, True)
+    sync()
+    el = time.perf_counter() - t0
+    build_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
+    return el, build_ms, float(loss.item()), (f"conditional GCN-VGAE+VQ train step on a minibatch stream: {fresh} resident minibatches round-robin, each step "
+                                              f"collates {G} graphs x {e} edges x {n} nodes on the device, builds both CSR pairs / transposes / gcn_norm / "
+                                              f"piece lists (one host read) and runs the optimizer step; in {args.in_dim}+{C}, latent {args.latent}, {args.codes} codes")
 
 
 def gather_ceiling_ms(graph, x_like, F):
@@ -370,7 +424,13 @@ def main():
     if args.scaling == "strong" and (args.workload != "cvgae" or args.graphs < world):
         raise SystemExit("--scaling strong: the cvgae workload with at least one graph per rank (the other workloads are one shard per GPU)")
     if args.workload == "cvgae":
-        el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
+        build_ms = None
+        if args.fresh_batches > 0:
+            if args.scaling != "weak":
+                raise SystemExit("--fresh-batches: weak scaling only (every rank streams its own minibatches)")
+            el, build_ms, last_loss, wl = run_cvgae_stream(args, dev, args.steps, args.warmup, args.fresh_batches, rank, world, barrier)
+        else:
+            el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
         el, rep = rank_report(el, dev, world, backend)
         if rank == 0:
             total_graphs = (args.graphs // world) * world if args.scaling == "strong" else args.graphs * world
@@ -378,6 +438,8 @@ def main():
                     "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
                     "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": wl, "parallelism": f"dp{world}"}, "loss": last_loss}
+            if build_ms is not None:
+                line["graph_build_ms"] = build_ms
             line.update(_finish_report(rep, args.steps))
             print(json.dumps(line))
         if world > 1:
@@ -494,6 +556,13 @@ def main():
                                  "workload": wl_c, "loss": loss_c}
 
             leg("cvgae", leg_cvgae)
+
+            def leg_stream():
+                el_s, build_ms, loss_s, wl_s = run_cvgae_stream(args, dev, 20, 3, 4)
+                line["cvgae_stream"] = {"ms_per_step": el_s / 20 * 1e3, "graph_build_ms": build_ms, "edges_per_s": args.graphs * args.edges_per_graph / (el_s / 20),
+                                        "steps": 20, "workload": wl_s, "loss": loss_s}
+
+            leg("cvgae_stream", leg_stream)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

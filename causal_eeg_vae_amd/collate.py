@@ -37,6 +37,7 @@ class CollatedBatch:
         dev = edge_indices[0].device
         _lib.require_cuda(*edge_indices)
         self.num_graphs = G = len(edge_indices)
+        self.nodes_per_graph = [int(n) for n in nodes_per_graph]
         self.ptr = _ptr(nodes_per_graph, dev)
         self.edge_ptr = _ptr([int(e.shape[1]) for e in edge_indices], dev)
         self.num_nodes = int(sum(int(n) for n in nodes_per_graph))
@@ -58,6 +59,23 @@ class CollatedBatch:
             setattr(self, key, val)
             setattr(self, key + "_batch", self.followed[key][1])
             setattr(self, key + "_ptr", kp)
+
+    def event_graph(self, edge_weight=None, with_dec=True):
+        """The collated batch as an EventGraph, built with ONE host synchronisation (models.EventGraph: both CSR pairs, their
+        piece lists and the layout check share one record).  For equal-sized graphs the check "no edge leaves its graph" is
+        evaluated on the device and lands in graph.checks[("intra", nodes_per_graph)], which ConditionalVGAEVQ consults instead
+        of testing (and synchronising) itself; `batch` is the block layout by construction."""
+        from .models import EventGraph
+        checks = None
+        sizes = set(self.nodes_per_graph)
+        if len(sizes) == 1 and self.nodes_per_graph[0] > 0:
+            n = int(self.nodes_per_graph[0])
+            ei, eb = self.edge_index, self.edge_batch
+            ok = ((ei[0] // n == eb) & (ei[1] // n == eb)).all() if ei.shape[1] else torch.ones((), dtype=torch.bool, device=ei.device)
+            checks = {("intra", n): ok}
+        g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks)
+        g.batch = self.batch
+        return g
 
     def separate(self, idx):
         """The idx-th graph back out of the collated storage (torch_geometric.data.separate): its edge_index with the node

@@ -28,9 +28,14 @@ EPS = 1e-15
 # Graph structure: canonical CSR (by dst, then src, then edge id) + its transpose, built once per graph
 # ==================================================================================================
 class CsrPair:
-    """A CSR grouped by destination and its transpose (grouped by source) with the value permutation."""
+    """A CSR grouped by destination and its transpose (grouped by source) with the value permutation.
 
-    def __init__(self, edge_index, num_nodes, self_loops):
+    Everything is built by kernels launched back to back - canonical CSR, transpose, the longest row of each orientation and
+    the piece lists of the long rows (ceeg_csr_long_items) - and what the host has to know (entry count, longest rows, piece
+    counts) arrives in ONE small device record read once by `finalize()`.  `defer=True` leaves that read to the caller, so that
+    several structures (EventGraph's two pairs, a collation's layout check) share a single host synchronisation."""
+
+    def __init__(self, edge_index, num_nodes, self_loops, defer=False):
         _lib.require_cuda(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -38,31 +43,53 @@ class CsrPair:
         dev = edge_index.device
         ei = edge_index.to(torch.int64).contiguous()
         E, N = ei.shape[1], int(num_nodes)
-        cap = E + (N if self_loops else 0)
+        cap = max(E + (N if self_loops else 0), 1)
         self.num_nodes, self.self_loops = N, bool(self_loops)
+        self._cap = cap
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-        col = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-        perm = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-        nnz_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.col = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.perm = torch.empty(cap, dtype=torch.int32, device=dev)
         ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
         _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
-                                    col.data_ptr(), perm.data_ptr(), nnz_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                    self.col.data_ptr(), self.perm.data_ptr(), None, ws.data_ptr(), ws.numel(),
                                     _lib.stream()), "ceeg_csr_build")
-        self.nnz = int(nnz_dev.item())  # one host sync at graph-construction time (never inside a step)
-        self.col, self.perm = col[: self.nnz], perm[: self.nnz]
+        # the transpose runs on the CAPACITY: the true entry count (input self-loops dropped, out-of-range ids skipped) stays
+        # on the device until finalize()
         self.t_rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
-        self.t_col = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)[: self.nnz]
-        self.t_perm = torch.empty(max(self.nnz, 1), dtype=torch.int32, device=dev)[: self.nnz]
-        ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(self.nnz, N), dev)
-        _lib.check(L.ceeg_csr_transpose(self.rowptr.data_ptr(), self.col.data_ptr(), self.nnz, N, self.t_rowptr.data_ptr(),
+        self.t_col = torch.empty(cap, dtype=torch.int32, device=dev)
+        self.t_perm = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(cap, N), dev)
+        _lib.check(L.ceeg_csr_transpose(self.rowptr.data_ptr(), self.col.data_ptr(), cap, N, self.t_rowptr.data_ptr(),
                                         self.t_col.data_ptr(), self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(),
                                         _lib.stream()), "ceeg_csr_transpose")
+        # row statistics + piece lists of both orientations -> one record [nnz, max_row, n_long, nnz, max_trow, n_tlong]
+        chunk = int(L.ceeg_decoder_codes_chunk())
+        icap = 3 * cap // chunk + 4
+        self._items = [torch.empty(icap, 4, dtype=torch.int32, device=dev) for _ in range(2)]
+        self._rec = torch.empty(6, dtype=torch.int64, device=dev)
+        ws = _lib.workspace(L.ceeg_csr_long_items_ws_bytes(N), dev)
+        for k, rp in enumerate((self.rowptr, self.t_rowptr)):
+            _lib.check(L.ceeg_csr_long_items(rp.data_ptr(), N, chunk, self._items[k].data_ptr(), icap, self._rec[3 * k:].data_ptr(),
+                                             ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_csr_long_items")
+        self._long = None
+        if not defer:
+            self.finalize()
 
-        # longest row of each orientation (graph-construction time): lets SpMM skip its long-row pass
-        self.max_row = int((self.rowptr[1:] - self.rowptr[:-1]).max().item()) if N > 0 else 0
-        self.max_trow = int((self.t_rowptr[1:] - self.t_rowptr[:-1]).max().item()) if N > 0 else 0
-
-        self._long = {}
+    def finalize(self, record=None):
+        """Take the host copy of the record (read here - the ONE host synchronisation of the construction - unless the caller
+        read it together with other records and passes it in) and cut the arrays to the true entry count."""
+        if self._long is not None:
+            return self
+        r = (self._rec.cpu() if record is None else record).tolist()
+        icap = self._items[0].shape[0]
+        if r[2] > icap or r[5] > icap:
+            raise _lib.CeegError("piece list capacity exceeded (internal bound 3 * nnz / chunk)")
+        self.nnz, self.max_row, self.max_trow = int(r[0]), int(r[1]), int(r[4])
+        self.col, self.perm = self.col[: self.nnz], self.perm[: self.nnz]
+        self.t_col, self.t_perm = self.t_col[: self.nnz], self.t_perm[: self.nnz]
+        self._long = {False: self._items[0][: r[2]] if r[2] else None, True: self._items[1][: r[5]] if r[5] else None}
+        self._items = None
+        return self
 
     @property
     def device(self):
@@ -70,19 +97,16 @@ class CsrPair:
 
     def long_items(self, transposed=False):
         """Piece list of the rows longer than ceeg_decoder_codes_chunk() entries (include/ceeg.h, ceeg_decoder_codes_* and
-        ceeg_spmm_csr_items); None when no row is that long.  Static per graph: built once (graph-construction work, one
-        host sync), never inside a step."""
-        key = bool(transposed)
-        if key not in self._long:
-            chunk = int(_lib.lib().ceeg_decoder_codes_chunk())
-            self._long[key] = build_long_items(self.t_rowptr if transposed else self.rowptr, chunk)
-        return self._long[key]
+        ceeg_spmm_csr_items); None when no row is that long.  Static per graph, filled on the device at construction."""
+        return self.finalize()._long[bool(transposed)]
 
 
 def build_long_items(rowptr, chunk):
     """int32 [n][4] = (lo, hi, chunk_index*2 + slot, row): every row longer than `chunk` entries cut at the GLOBAL positions
     k*chunk, rows ascending, pieces ascending; slot = 1 for the piece that starts its row in the middle of a chunk (a chunk
-    can hold the tail of one long row and the head of the next), else 0.  None when no row is that long."""
+    can hold the tail of one long row and the head of the next), else 0.  None when no row is that long.
+    Host-side (torch ops, synchronising) statement of what ceeg_csr_long_items fills on the device; kept as its checker and for
+    row-pointer arrays that do not come from a CsrPair."""
     rp = rowptr.long()
     rows = torch.nonzero((rp[1:] - rp[:-1]) > chunk).view(-1)
     if rows.numel() == 0:
@@ -102,13 +126,26 @@ def build_long_items(rowptr, chunk):
 class EventGraph:
     """An event graph (edges old_id -> new_id, /root/reference/scripts/dataset.py:147-153) prepared for the
     GCN encoder (`gcn`: A + I with symmetric normalisation) and the decoder (`dec`: the raw edges).
-    Build it once per graph / minibatch; every step reuses the structures."""
+    Build it once per graph / minibatch; every step reuses the structures.
 
-    def __init__(self, edge_index, num_nodes, edge_weight=None):
+    with_dec=True builds the decoder's pair in the same pass, and `checks` (name -> 0-d bool tensor on the device, e.g. a
+    collation's "no edge leaves its graph") is read with the same record: the whole construction then costs ONE host
+    synchronisation - what a loop that sees a new minibatch every step (scripts/run.py:310-326) wants.  Without them the decoder
+    pair is built on first use (a second synchronisation)."""
+
+    def __init__(self, edge_index, num_nodes, edge_weight=None, with_dec=False, checks=None):
         self.edge_index = edge_index
         self.num_nodes = int(num_nodes)
         self.num_edges = int(edge_index.shape[1])
-        self.gcn = CsrPair(edge_index, num_nodes, self_loops=True)
+        self.gcn = CsrPair(edge_index, num_nodes, self_loops=True, defer=True)
+        self._dec = CsrPair(edge_index, num_nodes, self_loops=False, defer=True) if with_dec else None
+        names = list(checks or {})
+        parts = [self.gcn._rec] + ([self._dec._rec] if with_dec else []) + [torch.stack([checks[k].reshape(()).to(torch.int64) for k in names])] * bool(names)
+        rec = torch.cat(parts).cpu()            # the one host synchronisation of the construction
+        self.gcn.finalize(rec[:6])
+        if with_dec:
+            self._dec.finalize(rec[6:12])
+        self.checks = {k: bool(v) for k, v in zip(names, rec[len(rec) - len(names):].tolist())} if names else {}
         L = _lib.lib()
         dev = edge_index.device
         ew = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
@@ -120,8 +157,6 @@ class EventGraph:
         # values in the transposed order, gathered once: the backward SpMM then streams them instead of chasing
         # val[t_perm[q]] (a dependent load in front of every row's gathers)
         self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
-        self.gcn.long_items(False), self.gcn.long_items(True)  # piece lists of the hub rows: graph-construction work
-        self._dec = None
 
     def edge_index_i32(self):
         """int32 copy of edge_index for the edge-list kernels (made once per graph)."""
@@ -133,7 +168,6 @@ class EventGraph:
     def dec(self):
         if self._dec is None:
             self._dec = CsrPair(self.edge_index, self.num_nodes, self_loops=False)
-            self._dec.long_items(False), self._dec.long_items(True)
         return self._dec
 
 
@@ -987,6 +1021,9 @@ class ConditionalVGAEVQ(nn.Module):
     def _intra_graph(graph, batch, mod):
         """True when `batch` is the block layout of equal-sized graphs (node n in graph n // mod) and no edge crosses
         graphs - checked once per graph object (graph-construction work, one host sync)."""
+        pre = getattr(graph, "checks", {}).get(("intra", int(mod)))   # a collation already checked it on the device
+        if pre is not None and getattr(graph, "batch", None) is batch:
+            return pre
         key = (batch.data_ptr(), int(mod))
         cache = getattr(graph, "_intra", None)
         if cache is None or cache[0] != key:

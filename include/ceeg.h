@@ -41,7 +41,7 @@ enum {
 enum { CEEG_F32 = 0, CEEG_BF16 = 1 };
 
 int ceeg_version(void);
-/* Hash of the sources this binary was built from (csrc/*.hip, csrc/*.h, this header; causal_eeg_vae_amd/_srchash.py computes
+/* Hash of the sources this binary was built from (the .hip and .h files under csrc/ and this header; causal_eeg_vae_amd/_srchash.py computes
  * the same value for a source tree).  No reference counterpart: it lets smoke() / the tests refuse a stale libceeg.so. */
 const char* ceeg_source_hash(void);
 const char* ceeg_strerror(int code);

@@ -39,6 +39,49 @@ def test_csr_build_transpose_bit_exact(N, E, self_loops, hubs):
     # sortedness property (the canonical (dst, src) order)
     key = np.repeat(np.arange(N), np.diff(rowptr)) * (N + 1) + p.col.cpu().numpy()
     assert (np.diff(key) >= 0).all()
+    # the record the device filled (one host read): longest rows and the piece lists of the long rows, against a plain walk
+    from causal_eeg_vae_amd.models import build_long_items
+    chunk = 256
+    for rp, mr, items in ((rowptr, p.max_row, p.long_items(False)), (t_rowptr, p.max_trow, p.long_items(True))):
+        lens = np.diff(rp)
+        assert mr == (int(lens.max()) if N else 0)
+        want = []
+        for r in np.nonzero(lens > chunk)[0]:
+            lo, hi = int(rp[r]), int(rp[r + 1])
+            for c in range(lo // chunk, (hi - 1) // chunk + 1):
+                want.append((max(lo, c * chunk), min(hi, (c + 1) * chunk), 2 * c + int(c == lo // chunk and lo != c * chunk), int(r)))
+        if not want:
+            assert items is None
+        else:
+            assert items.cpu().numpy().tolist() == [list(w) for w in want]
+            assert torch.equal(items, build_long_items(torch.from_numpy(rp.astype(np.int32)).cuda(), chunk))
+
+
+def test_event_graph_single_read_construction():
+    """EventGraph(with_dec=True, checks=...) builds both pairs and reads every host-side quantity in one record; ids outside
+    [0, N) and input self-loops make the entry counts data-dependent (nnz < capacity) and the structures still equal the
+    oracle's."""
+    from causal_eeg_vae_amd import EventGraph
+    from oracle import ref_torch
+    N, E = 3000, 50000
+    src, dst = _rand_graph(N, E, 5, hubs=600)
+    src[:5] = -1; dst[5:9] = N + 3                        # skipped by the builder
+    ei = torch.from_numpy(np.stack([src, dst])).cuda()
+    g = EventGraph(ei, N, with_dec=True, checks={"yes": torch.ones((), dtype=torch.bool, device="cuda"), "no": (ei[0] > N + 5).any()})
+    assert g.checks == {"yes": True, "no": False} and g._dec is not None
+    ok = (src >= 0) & (src < N) & (dst >= 0) & (dst < N)
+    eid = np.nonzero(ok)[0]
+    for pair, loops in ((g.gcn, True), (g.dec, False)):
+        rowptr, col, perm = ref_torch.csr_build_np(src[ok], dst[ok], N, loops)
+        assert pair.nnz == rowptr[-1] < E + (N if loops else 0)
+        np.testing.assert_array_equal(pair.rowptr.cpu().numpy(), rowptr)
+        np.testing.assert_array_equal(pair.col.cpu().numpy(), col)
+        np.testing.assert_array_equal(pair.perm.cpu().numpy(), np.where(perm >= 0, eid[np.maximum(perm, 0)], -1))
+        t_rowptr, t_col, t_perm = ref_torch.csr_transpose_np(rowptr, col, N)
+        np.testing.assert_array_equal(pair.t_rowptr.cpu().numpy(), t_rowptr)
+        np.testing.assert_array_equal(pair.t_col.cpu().numpy(), t_col)
+        np.testing.assert_array_equal(pair.t_perm.cpu().numpy(), t_perm)
+        assert pair.max_row == int(np.diff(rowptr).max()) and pair.max_trow == int(np.diff(t_rowptr).max())
 
 
 @pytest.mark.parametrize("weighted", [False, True])

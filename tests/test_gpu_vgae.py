@@ -918,3 +918,42 @@ def test_pool_kernels_reduced_precision_and_odd_widths():
         (out * x.cuda()).sum().backward()
         _close(out, ref)
         _close(b.grad, a.grad)
+
+
+def test_minibatch_stream_construction_equals_static_graph():
+    """CollatedBatch.event_graph() - collation, both CSR pairs, piece lists and the "no edge leaves its graph" check in ONE host
+    read (what bench.py --fresh-batches times per step) - feeds the conditional step exactly like the separately built
+    EventGraph: loss and every gradient bit for bit; a batch with an edge crossing graphs is flagged on the device and takes the
+    concatenating decoder (same result as the static path on that batch)."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ, EventGraph
+    from causal_eeg_vae_amd.collate import CollatedBatch
+    G, n, e, Fi, C, D, n_e = 6, 400, 5000, 28, 4, 64, 64
+    eis = [torch.from_numpy(_graph(n, e, 40 + g)).cuda() for g in range(G)]
+    torch.manual_seed(2)
+    model = ConditionalVGAEVQ(Fi, C, D, n_e, 0.25).cuda()
+    with torch.no_grad():
+        model.vector_quantization.embedding.weight.normal_(0, 0.3)
+    x, cond = torch.randn(G * n, Fi, device="cuda"), torch.randn(G, C, device="cuda")
+
+    def run(graph, batch):
+        model.zero_grad(set_to_none=True)
+        loss, aux = model(x, graph, batch, cond, step=1, nodes_per_graph=n)
+        loss.backward()
+        return loss.detach().clone(), [p.grad.clone() for p in model.parameters()], aux
+
+    cb = CollatedBatch(eis, [n] * G)
+    g_stream = cb.event_graph()
+    assert g_stream.checks == {("intra", n): True} and g_stream._dec is not None
+    assert ConditionalVGAEVQ._intra_graph(g_stream, cb.batch, n) is True
+    l1, g1, _ = run(g_stream, cb.batch)
+    l2, g2, _ = run(EventGraph(cb.edge_index, cb.num_nodes), cb.batch)
+    assert torch.equal(l1, l2) and all(torch.equal(a, b) for a, b in zip(g1, g2))
+    # one edge of graph 0 re-pointed into graph 1 (ids are local: n + 3 lies outside graph 0's block)
+    bad = [e_.clone() for e_ in eis]
+    bad[0][1, 0] = n + 3
+    cb2 = CollatedBatch(bad, [n] * G)
+    g_bad = cb2.event_graph()
+    assert g_bad.checks == {("intra", n): False}
+    l3, g3, _ = run(g_bad, cb2.batch)
+    l4, g4, _ = run(EventGraph(cb2.edge_index, cb2.num_nodes), cb2.batch)
+    assert torch.equal(l3, l4) and all(torch.equal(a, b) for a, b in zip(g3, g4))
