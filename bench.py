@@ -479,19 +479,42 @@ def main():
         ms = el / args.steps * 1e3
         F = 2 * args.latent
         nnz = graph.gcn.nnz
-        # compulsory bytes of one SpMM pass of width F
+        # compulsory bytes of one SpMM pass of width F.  The two F-wide launches of a step are the layer-2
+        # aggregation and its transposed pass; the latter also applies the ReLU backward mask in its epilogue (it reads the
+        # [N, F] activation once more: compulsory bytes of the fused operation, counted for that launch only).
         spmm_bytes = nnz * 8 + (N + 1) * 4 + 2 * N * F * 4
-        launches, spmm_ms = prof.get(f"spmm_F{F}", (0, float("nan")))  # layer-2 aggregation (fwd) and its transposed pass (bwd)
-        achieved = spmm_bytes / (spmm_ms * 1e-3) / 1e9
-        # HBM-side bytes per launch from the rocprofv3 PMC passes of this round (profiles/r02_spmm_bound.txt);
-        # counters cannot be read from inside the process, so the figure is reported only for the workload it was
-        # measured on
-        traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_spmm_traffic.json")
-        if os.path.exists(tpath):
-            t = json.load(open(tpath))
-            if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F):
-                traffic = t["traffic_bytes"]
+        n1, ms1 = prof.get(f"spmm_F{F}", (0, 0.0))
+        n2, ms2 = prof.get(f"spmm_masked_F{F}", (0, 0.0))
+        launches = n1 + n2
+        total_bytes = n1 * spmm_bytes + n2 * (spmm_bytes + N * F * 4)
+        spmm_ms = (n1 * ms1 + n2 * ms2) / launches if launches else float("nan")
+        achieved = total_bytes / launches / (spmm_ms * 1e-3) / 1e9 if launches else float("nan")
+        # HBM-side bytes per launch from the rocprofv3 PMC passes (profiles/r03_traffic.json, made by scripts/pmc_traffic.py from
+        # separate --pmc runs of this command); counters cannot be read from inside the process, so the figures are reported
+        # only for the workload they were measured on
+        traffic = dec_traffic = None
+        here = os.path.dirname(os.path.abspath(__file__))
+        for name in ("r03_traffic.json", "r02_spmm_traffic.json"):
+            tpath = os.path.join(here, "profiles", name)
+            if os.path.exists(tpath):
+                t = json.load(open(tpath))
+                if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F) and t.get("negatives", args.negatives) == args.negatives:
+                    traffic = t["traffic_bytes"]
+                    dec_traffic = t.get("decoder_traffic_bytes")
+                break
+        # the decoder of the step that ran (HBM-bound; north star: "HBM GB/s ... for SpMM and the decoder"):
+        # algorithmic bytes = every list entry / record / key read or written ONCE + the [N, D] gradient, over the summed
+        # HIP-event time of its launches
+        D_lat, Ed = args.latent, graph.dec.nnz
+        dec_keys = ["decoder_fwd", "decoder_bwd", "neg_sample", "pair_bce_fwd", "pair_bce_bwd"]
+        dec_ms = sum(prof[k][1] * prof[k][0] for k in dec_keys if k in prof) / max(args.steps, 1)
+        if args.negatives == "uniform":
+            dec_bytes = (Ed * 20 + N * 12) + (Ed * (2 * 16 + 4) + N * D_lat * 4) + E * 8 + (E * 16 + N * 4) + (E * 8 + 2 * N * D_lat * 4)
+            dec_what = ("code-form decoder, positives (ceeg_decoder_codes_fwd/_bwd) + negative_sampling (ceeg_neg_sample_uniform_filtered) + "
+                        "sampled pairs (ceeg_pair_bce_codes_fwd/_bwd incl. the incidence sort)")
+        else:
+            dec_bytes = (Ed * 20 + N * 12) + (Ed * (3 * 16 + 4) + N * D_lat * 4)
+            dec_what = "code-form decoder with permutation-structured negatives (ceeg_decoder_codes_fwd/_bwd)"
         neg_label = ("1:1 permutation-structured negatives (sigma affine per step, pairs colliding with an edge masked)" if args.negatives == "sigma"
                      else "1:1 uniform negatives (negative_sampling: E pairs from ceeg_neg_sample_uniform every step, their incidences grouped by one radix sort per step)")
         line = {"metric": "VGAE train edges/sec", "value": E * world / (el / args.steps), "unit": "edges/s", "n_gpus": world,
@@ -502,10 +525,17 @@ def main():
                            "parallelism": f"dp{world}",
                            "dense_products": ("fp32 library GEMMs (hipBLASLt / rocBLAS), kernels chosen by the package's TunableOp table "
                                               "for these shapes" if tuned else "fp32 library GEMMs (hipBLASLt), library heuristic")},
-                "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr F={F} (spmm_rows_kernel<64> + long-row pieces)",
+                "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr_items / ceeg_spmm_csr_masked F={F} (spmm_rows_kernel<64> + long-row pieces)",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": traffic, "launches_timed": launches, "avg_launch_ms": spmm_ms,
-                             "algorithmic_bytes_per_launch": spmm_bytes},
+                             "algorithmic_bytes_per_launch": total_bytes / launches if launches else None,
+                             "launches": {"aggregation": [n1, ms1], "transposed_with_relu_mask": [n2, ms2]},
+                             "hbm_side_GBps": (traffic / (spmm_ms * 1e-3) / 1e9) if traffic else None,
+                             "hbm_side_frac": (traffic / (spmm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None},
+                "roofline_decoder": {"bound": "hbm", "kernel": dec_what, "achieved": dec_bytes / (dec_ms * 1e-3) / 1e9 if dec_ms else None,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": dec_bytes / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if dec_ms else None,
+                                     "traffic": dec_traffic, "ms_per_step": dec_ms, "algorithmic_bytes_per_step": dec_bytes,
+                                     "hbm_side_GBps": (dec_traffic / (dec_ms * 1e-3) / 1e9) if (dec_traffic and dec_ms) else None},
                 "loss": float(loss.item())}
         line.update(_finish_report(rep, args.steps))
         if world == 1 and not args.no_extras:

@@ -98,6 +98,8 @@ struct CeegSpmmEx {
   int64_t n_long_items = 0;
   int nt = 0;                     // bit 0: non-temporal stores of out; bit 1: non-temporal loads of the col / val streams
   const int32_t* xidx = nullptr;  // row indirection for X (after the column map): gather X[xidx[c]] - X is then a small table
+  const float* mask = nullptr;    // [N, ld_mask]: the finished row is multiplied by (mask[r, f] > 0) - a ReLU's backward mask, applied
+  int64_t ld_mask = 0;            // to the gradient the pass produces (the mask row is fetched before the gathers, off the critical path)
 };
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
                      const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,

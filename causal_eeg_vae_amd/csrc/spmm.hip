@@ -258,6 +258,8 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     const int64_t r = base_cur + wave;
     if (r < r_end) {
       float4 acc;
+      float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (ex.mask && lane < LPR && fl_ok) mk = *reinterpret_cast<const float4*>(ex.mask + r * ex.ld_mask + foff);  // in flight under the gathers
       if (p_hi - p_lo <= SPMM_CHUNK) {
         acc = seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
       } else {
@@ -293,6 +295,10 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         }
         if (relu) {
           acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+        }
+        if (ex.mask) {  // g * (y > 0): exactly what ceeg_relu_bwd_colsum writes
+          acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
+          acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
         }
         if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
           __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
@@ -574,5 +580,24 @@ extern "C" int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, co
   ex.long_items = n_long > 0 ? long_items : no_items;  // non-NULL: "the list is authoritative" (host pointer never read when empty)
   ex.n_long_items = n_long;
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, bias, relu, accumulate, out, ldo, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream), ex);
+}
+
+extern "C" int ceeg_spmm_csr_masked(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                                    const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* mask, int64_t ld_mask,
+                                    float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items, int64_t n_long,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  if (!mask || ld_mask < F || (ld_mask % 4) != 0 || !ceeg_aligned(mask, 16)) return CEEG_EINVAL;
+  if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
+  if (max_row_nnz < 0 || (max_row_nnz > SPMM_CHUNK && n_long == 0)) return CEEG_EINVAL;
+  static const int32_t no_items[4] = {0, 0, 0, 0};
+  CeegSpmmEx ex;
+  ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
+  ex.long_items = n_long > 0 ? long_items : no_items;
+  ex.n_long_items = n_long;
+  ex.mask = mask;
+  ex.ld_mask = ld_mask;
+  return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, nullptr, 0, 0, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }

@@ -140,7 +140,9 @@ class EventGraph:
         self.gcn = CsrPair(edge_index, num_nodes, self_loops=True, defer=True)
         self._dec = CsrPair(edge_index, num_nodes, self_loops=False, defer=True) if with_dec else None
         names = list(checks or {})
-        parts = [self.gcn._rec] + ([self._dec._rec] if with_dec else []) + [torch.stack([checks[k].reshape(()).to(torch.int64) for k in names])] * bool(names)
+        parts = [self.gcn._rec] + ([self._dec._rec] if with_dec else [])
+        if names:
+            parts.append(torch.stack([checks[k].reshape(()).to(torch.int64) for k in names]))
         rec = torch.cat(parts).cpu()            # the one host synchronisation of the construction
         self.gcn.finalize(rec[:6])
         if with_dec:
@@ -177,15 +179,25 @@ def _as_graph(g, num_nodes):
     return EventGraph(g, num_nodes)
 
 
-def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1, items=False, xidx=None):
+def _spmm(rowptr, col, val, vperm, x, n_rows, bias=None, relu=False, out=None, accumulate=False, max_row=-1, items=False, xidx=None, mask=None):
     """items: False = let the kernel find the long rows; None / int32 [n,4] = the graph's piece list (CsrPair.long_items).
-    xidx (int32 [n_rows]): x is a TABLE and node c's row is x[xidx[c]] (ceeg_spmm_csr_table; no bias / relu there)."""
+    xidx (int32 [n_rows]): x is a TABLE and node c's row is x[xidx[c]] (ceeg_spmm_csr_table; no bias / relu there).
+    mask ([n_rows, F] fp32, with a piece list): the finished rows are multiplied by (mask > 0) (ceeg_spmm_csr_masked)."""
     L = _lib.lib()
     nnz = col.shape[0]
     F = x.shape[1]
     if out is None:
         out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
     ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
+    if mask is not None:
+        if items is False or max_row < 0 or bias is not None or relu or accumulate or xidx is not None:
+            raise ValueError("the masked SpMM takes the graph's piece list and no bias / relu / accumulate / table")
+        with _lib.timed(f"spmm_masked_F{F}"):
+            _lib.check(L.ceeg_spmm_csr_masked(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
+                                              n_rows, nnz, F, mask.data_ptr(), mask.stride(0), out.data_ptr(), out.stride(0), int(max_row),
+                                              _lib.ptr(items), 0 if items is None else items.shape[0], ws.data_ptr(), ws.numel(),
+                                              _lib.stream()), "ceeg_spmm_csr_masked")
+        return out
     if xidx is not None:
         with _lib.timed(f"spmm_table_F{F}"):
             _lib.check(L.ceeg_spmm_csr_table(rowptr.data_ptr(), col.data_ptr(), val.data_ptr(), _lib.ptr(vperm), x.data_ptr(), x.stride(0),
@@ -230,22 +242,6 @@ def _relu_bwd_colsum(g, y):
     return gm, out
 
 
-# Column sums a producer kernel already holds for a gradient tensor it hands to autograd (the fused reparam + VQ backward
-# leaves the encoder head's bias gradient).  The hint rides ON the gradient tensor itself (an attribute of the tensor object,
-# which autograd carries to the consuming node) together with the tensor's version counter: if autograd accumulates a second
-# gradient into the buffer (in place: the version moves; out of place: a new tensor without the attribute) or a hook edits
-# it, the hint no longer matches and the consumer recomputes the column sums.  No module-level state.
-def _offer_colsum(t, colsum):
-    t._ceeg_colsum = (colsum, t._version, tuple(t.shape))
-
-
-def _take_colsum(t):
-    ent = getattr(t, "_ceeg_colsum", None)
-    if ent is None or ent[1] != t._version or ent[2] != tuple(t.shape) or not t.is_contiguous():
-        return None
-    return ent[0]
-
-
 class _GcnAggregate(torch.autograd.Function):
     """out = act(A_hat @ h + b); backward dh = A_hat^T @ g through the transposed CSR (values via t_perm)."""
 
@@ -268,9 +264,7 @@ class _GcnAggregate(torch.autograd.Function):
             (out,) = ctx.saved_tensors
             grad, dbias = _relu_bwd_colsum(grad, out)
         else:
-            dbias = (_take_colsum(grad) if ctx.has_bias else None)
-            if dbias is None and ctx.has_bias:
-                dbias = _colsum(grad)
+            dbias = _colsum(grad) if ctx.has_bias else None
         dh = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, grad, graph.num_nodes, max_row=g.max_trow, items=g.long_items(True)) if ctx.needs_input_grad[0] else None
         return dh, dbias, None, None
 
@@ -289,6 +283,30 @@ def _split_k(n):
     return 1
 
 
+def _linear_fwd(x, weight, bias, relu):
+    """y = act(x @ W^T + b) in NN form; bias + ReLU in the GEMM epilogue when both are there."""
+    wt = weight.t().contiguous()  # [in, out]; out*in floats
+    if relu and bias is not None and os.environ.get("CEEG_GEMM_EPILOGUE", "1") == "1":
+        return torch._addmm_activation(bias, x, wt)  # hipBLASLt bias+ReLU epilogue: no extra pass over [N, out]
+    y = torch.mm(x, wt) if bias is None else torch.addmm(bias, x, wt)
+    if relu:
+        L = _lib.lib()
+        with _lib.timed("bias_relu"):
+            _lib.check(L.ceeg_bias_relu(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], None, 1, _lib.stream()), "ceeg_bias_relu")
+    return y
+
+
+def _weight_grad(x, g):
+    """dW = g^T x for a tall x [N, in] and g [N, out]: the N-deep reduction split over K into a batched product whose partial
+    results are summed in a fixed order (deterministic)."""
+    n = x.shape[0]
+    s = _split_k(n)
+    if s > 1:
+        # x^T g per slice (the faster of the two orientations in hipBLASLt for these shapes), transposed at the end
+        return torch.bmm(x.contiguous().view(s, n // s, -1).transpose(1, 2), g.view(s, n // s, -1)).sum(dim=0).t()
+    return g.t() @ x
+
+
 class _Linear(torch.autograd.Function):
     """y = x @ W^T (+ b) for a tall-skinny x [N, in] and a small W [out, in], arranged for hipBLASLt's fast
     fp32 kernels (measured on MI355X, N = 1M, 256x256): every product is issued in NN form, and the weight
@@ -297,15 +315,7 @@ class _Linear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu=False):
-        wt = weight.t().contiguous()  # [in, out]; out*in floats
-        if relu and bias is not None and os.environ.get("CEEG_GEMM_EPILOGUE", "1") == "1":
-            y = torch._addmm_activation(bias, x, wt)  # hipBLASLt bias+ReLU epilogue: no extra pass over [N, out]
-        else:
-            y = torch.mm(x, wt) if bias is None else torch.addmm(bias, x, wt)
-            if relu:
-                L = _lib.lib()
-                with _lib.timed("bias_relu"):
-                    _lib.check(L.ceeg_bias_relu(y.data_ptr(), y.stride(0), y.shape[0], y.shape[1], None, 1, _lib.stream()), "ceeg_bias_relu")
+        y = _linear_fwd(x, weight, bias, relu)
         if relu:
             ctx.save_for_backward(x, weight, y)
         else:
@@ -323,18 +333,37 @@ class _Linear(torch.autograd.Function):
             x, weight = ctx.saved_tensors
             g = g.contiguous()
         dx = torch.mm(g, weight) if ctx.needs_input_grad[0] else None  # [N,out] @ [out,in]: NN
-        dw = None
-        if ctx.needs_input_grad[1]:
-            n = x.shape[0]
-            s = _split_k(n)
-            if s > 1:
-                # x^T g per slice (the faster of the two orientations in hipBLASLt for these shapes), transposed at the end
-                dw = torch.bmm(x.contiguous().view(s, n // s, -1).transpose(1, 2), g.view(s, n // s, -1)).sum(dim=0).t()
-            else:
-                dw = g.t() @ x
+        dw = _weight_grad(x, g) if ctx.needs_input_grad[1] else None
         if db is None and ctx.has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g)
         return dx, dw, (db if ctx.has_bias else None), None
+
+
+class _LinearReluAggregate(torch.autograd.Function):
+    """ah = A_hat @ relu(ax @ W^T + b): the first layer's dense half (aggregate-first form, ax = A_hat x) and the SECOND
+    layer's aggregation as one autograd node, so that the ReLU's backward mask is applied in the epilogue of the transposed
+    pass that produces dh (ceeg_spmm_csr_masked) instead of a separate read-modify-write of the [N, H] gradient."""
+
+    @staticmethod
+    def forward(ctx, ax, weight, bias, graph):
+        _lib.require_cuda(ax)
+        h = _linear_fwd(ax, weight, bias, True)
+        g = graph.gcn
+        ah = _spmm(g.rowptr, g.col, graph.gcn_val, None, h, graph.num_nodes, max_row=g.max_row, items=g.long_items(False))
+        ctx.save_for_backward(ax, weight, h)
+        ctx.graph = graph
+        return ah
+
+    @staticmethod
+    def backward(ctx, dah):
+        ax, weight, h = ctx.saved_tensors
+        graph, g = ctx.graph, ctx.graph.gcn
+        gm = _spmm(g.t_rowptr, g.t_col, graph.gcn_tval, None, dah.contiguous(), graph.num_nodes, max_row=g.max_trow, items=g.long_items(True),
+                   mask=h)                                            # (A_hat^T dah) * (h > 0)
+        db = _colsum(gm) if ctx.needs_input_grad[2] else None
+        dw = _weight_grad(ax, gm) if ctx.needs_input_grad[1] else None
+        dax = torch.mm(gm, weight) if ctx.needs_input_grad[0] else None
+        return dax, dw, db, None
 
 
 class _Lin(nn.Module):
@@ -416,39 +445,75 @@ class _ReparamKL(torch.autograd.Function):
         return dml[:, :D], dml[:, D:], None, None, None, None
 
 
+def _rvq_forward(ml, eps, seed, training, log_var, weight, beta):
+    """ceeg_reparam_kl_fwd + ceeg_vq_forward on the fused [N, 2D] encoder output -> (z, kl, scal[loss, ppl], z_q, idx, epsc, wc)."""
+    L = _lib.lib()
+    N, D = ml.shape[0], ml.shape[1] // 2
+    mu_v, ls_v = ml[:, :D], ml[:, D:]
+    dev = ml.device
+    epsc = None if eps is None else eps.contiguous()
+    wc = weight.contiguous()
+    n_e = wc.shape[0]
+    if wc.shape[1] != D or wc.dtype != torch.float32:
+        raise ValueError("the codebook must be float32 [n_e, latent]")
+    z = torch.empty(N, D, dtype=torch.float32, device=dev)
+    kl = torch.empty((), dtype=torch.float32, device=dev)
+    ws = _lib.workspace(L.ceeg_reparam_kl_ws_bytes(N, D), dev)
+    _lib.check(L.ceeg_reparam_kl_fwd(mu_v.data_ptr(), mu_v.stride(0), ls_v.data_ptr(), ls_v.stride(0), _lib.ptr(epsc), int(seed),
+                                     N, D, float(MAX_LOGSTD), int(log_var), int(training), z.data_ptr(), kl.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_kl_fwd")
+    z_q = torch.empty_like(z)
+    idx = torch.empty(N, 1, dtype=torch.int64, device=dev)
+    scal = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = _lib.workspace(L.ceeg_vq_forward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
+    _lib.check(L.ceeg_vq_forward(z.data_ptr(), wc.data_ptr(), N, n_e, D, _lib.CEEG_F32, float(beta), z_q.data_ptr(), idx.data_ptr(),
+                                 scal[0:].data_ptr(), scal[1:].data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream()),
+               "ceeg_vq_forward")
+    return z, kl, scal, z_q, idx, epsc, wc
+
+
+def _rvq_backward(ml, epsc, wc, idx, z, cfg, g_z, g_kl, g_loss, g_zq, want_dW, want_dml, want_colsum):
+    """ceeg_vq_backward (codebook gradient) + ceeg_reparam_vq_bwd -> (dml [N, 2D], its column sums or None, dW)."""
+    seed, training, log_var, beta = cfg
+    L = _lib.lib()
+    N, D = z.shape
+    n_e = wc.shape[0]
+    dev = z.device
+    s = None if g_loss is None else g_loss.reshape(1).to(torch.float32).contiguous()
+    gk = None if g_kl is None else g_kl.reshape(1).contiguous()
+    dW = None
+    if want_dW:
+        dW = torch.empty_like(wc)
+        sw = s if s is not None else torch.zeros(1, dtype=torch.float32, device=dev)
+        ws = _lib.workspace(L.ceeg_vq_backward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
+        _lib.check(L.ceeg_vq_backward(z.data_ptr(), wc.data_ptr(), idx.data_ptr(), None, sw.data_ptr(), N, n_e, D, _lib.CEEG_F32, beta,
+                                      None, dW.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_vq_backward")
+    dml = colsum = None
+    if want_dml:
+        dml = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
+        colsum = torch.empty(2 * D, dtype=torch.float32, device=dev) if want_colsum else None
+        gq = None if g_zq is None else g_zq.contiguous()
+        gz = None if g_z is None else g_z.contiguous()
+        ws = _lib.workspace(L.ceeg_reparam_vq_bwd_ws_bytes(N, D), dev)
+        with _lib.timed("reparam_vq_bwd"):
+            _lib.check(L.ceeg_reparam_vq_bwd(ml.data_ptr(), ml.stride(0), ml[:, D:].data_ptr(), ml.stride(0), _lib.ptr(epsc), seed,
+                                             _lib.ptr(gq), _lib.ptr(gz), wc.data_ptr(), idx.data_ptr(), n_e, _lib.ptr(s), _lib.ptr(gk),
+                                             N, D, float(MAX_LOGSTD), log_var, training, dml.data_ptr(), 2 * D, dml[:, D:].data_ptr(),
+                                             2 * D, _lib.ptr(colsum), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_vq_bwd")
+    return dml, colsum, dW
+
+
 class _ReparamVQ(torch.autograd.Function):
     """(z, kl, vq_loss, z_q, perplexity, idx) = VectorQuantizer(reparametrize(mu | logstd)) with ONE fused backward pass
-    (ceeg_reparam_vq_bwd): dz of the quantiser is never written, z is recomputed from (mu, logstd, eps/seed), and the
-    column sums of the [N, 2D] gradient (the encoder head's bias gradient) come out of the same pass.
+    (ceeg_reparam_vq_bwd): dz of the quantiser is never written and z is recomputed from (mu, logstd, eps/seed).
     `ml` is the fused [N, 2D] encoder output (mu | logstd); forward = ceeg_reparam_kl_fwd + ceeg_vq_forward as
     _ReparamKL / _VQFunction (scripts/models.py:30-32 order: encoder -> latent -> vector_quantization)."""
 
     @staticmethod
     def forward(ctx, ml, eps, seed, training, log_var, weight, beta):
         _lib.require_cuda(ml, weight)
-        L = _lib.lib()
         ml = ml.contiguous()
-        N, D = ml.shape[0], ml.shape[1] // 2
-        mu_v, ls_v = ml[:, :D], ml[:, D:]
-        dev = ml.device
-        epsc = None if eps is None else eps.contiguous()
-        wc = weight.contiguous()
-        n_e = wc.shape[0]
-        if wc.shape[1] != D or wc.dtype != torch.float32:
-            raise ValueError("the codebook must be float32 [n_e, latent]")
-        z = torch.empty(N, D, dtype=torch.float32, device=dev)
-        kl = torch.empty((), dtype=torch.float32, device=dev)
-        ws = _lib.workspace(L.ceeg_reparam_kl_ws_bytes(N, D), dev)
-        _lib.check(L.ceeg_reparam_kl_fwd(mu_v.data_ptr(), mu_v.stride(0), ls_v.data_ptr(), ls_v.stride(0), _lib.ptr(epsc), int(seed),
-                                         N, D, float(MAX_LOGSTD), int(log_var), int(training), z.data_ptr(), kl.data_ptr(),
-                                         ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_kl_fwd")
-        z_q = torch.empty_like(z)
-        idx = torch.empty(N, 1, dtype=torch.int64, device=dev)
-        scal = torch.empty(2, dtype=torch.float32, device=dev)
-        ws = _lib.workspace(L.ceeg_vq_forward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
-        _lib.check(L.ceeg_vq_forward(z.data_ptr(), wc.data_ptr(), N, n_e, D, _lib.CEEG_F32, float(beta), z_q.data_ptr(), idx.data_ptr(),
-                                     scal[0:].data_ptr(), scal[1:].data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream()),
-                   "ceeg_vq_forward")
+        z, kl, scal, z_q, idx, epsc, wc = _rvq_forward(ml, eps, seed, training, log_var, weight, beta)
         ctx.save_for_backward(ml, epsc, wc, idx, z)
         ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
         loss_t, ppl_t = scal[0], scal[1]
@@ -461,34 +526,46 @@ class _ReparamVQ(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_z, g_kl, g_loss, g_zq, _g_ppl, _g_idx):
         ml, epsc, wc, idx, z = ctx.saved_tensors
-        seed, training, log_var, beta = ctx.cfg
-        L = _lib.lib()
-        N, D = z.shape
-        n_e = wc.shape[0]
-        dev = z.device
-        s = None if g_loss is None else g_loss.reshape(1).to(torch.float32).contiguous()
-        gk = None if g_kl is None else g_kl.reshape(1).contiguous()
-        dW = None
-        if ctx.needs_input_grad[5]:
-            dW = torch.empty_like(wc)
-            sw = s if s is not None else torch.zeros(1, dtype=torch.float32, device=dev)
-            ws = _lib.workspace(L.ceeg_vq_backward_ws_bytes(N, n_e, D, _lib.CEEG_F32), dev)
-            _lib.check(L.ceeg_vq_backward(z.data_ptr(), wc.data_ptr(), idx.data_ptr(), None, sw.data_ptr(), N, n_e, D, _lib.CEEG_F32, beta,
-                                          None, dW.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_vq_backward")
-        dml = None
-        if ctx.needs_input_grad[0]:
-            dml = torch.empty(N, 2 * D, dtype=torch.float32, device=dev)
-            colsum = torch.empty(2 * D, dtype=torch.float32, device=dev)
-            gq = None if g_zq is None else g_zq.contiguous()
-            gz = None if g_z is None else g_z.contiguous()
-            ws = _lib.workspace(L.ceeg_reparam_vq_bwd_ws_bytes(N, D), dev)
-            with _lib.timed("reparam_vq_bwd"):
-                _lib.check(L.ceeg_reparam_vq_bwd(ml.data_ptr(), ml.stride(0), ml[:, D:].data_ptr(), ml.stride(0), _lib.ptr(epsc), seed,
-                                                 _lib.ptr(gq), _lib.ptr(gz), wc.data_ptr(), idx.data_ptr(), n_e, _lib.ptr(s), _lib.ptr(gk),
-                                                 N, D, float(MAX_LOGSTD), log_var, training, dml.data_ptr(), 2 * D, dml[:, D:].data_ptr(),
-                                                 2 * D, colsum.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_reparam_vq_bwd")
-            _offer_colsum(dml, colsum)
+        dml, _, dW = _rvq_backward(ml, epsc, wc, idx, z, ctx.cfg, g_z, g_kl, g_loss, g_zq, ctx.needs_input_grad[5], ctx.needs_input_grad[0], False)
         return dml, None, None, None, None, dW, None
+
+
+class _HeadReparamVQ(torch.autograd.Function):
+    """The encoder head's dense half and everything up to the quantiser as ONE autograd node:
+        ml = ah @ [W_mu | W_sigma]^T + [b_mu | b_sigma]      (ah = A_hat h: the head in aggregate-first form)
+        (z, kl) = reparametrize + KL;  (vq_loss, z_q, perplexity, idx) = VectorQuantizer(z)
+    Its backward takes the bias gradient from the column sums ceeg_reparam_vq_bwd leaves in the same pass - a real output of
+    this function, not a hint passed between nodes - and returns dah = dml W, dW = dml^T ah (split-K, fixed order).
+    `ml` is also an output (the caller may attach a loss to mu | logstd): a gradient arriving for it is added to dml and the
+    column sums are then recomputed."""
+
+    @staticmethod
+    def forward(ctx, ah, wcat, bcat, eps, seed, training, log_var, weight, beta):
+        _lib.require_cuda(ah, weight)
+        ml = _linear_fwd(ah, wcat, bcat, False)
+        z, kl, scal, z_q, idx, epsc, wc = _rvq_forward(ml, eps, seed, training, log_var, weight, beta)
+        ctx.save_for_backward(ah, wcat, ml, epsc, wc, idx, z)
+        ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
+        loss_t, ppl_t = scal[0], scal[1]
+        ctx.mark_non_differentiable(ppl_t, idx)
+        ctx.set_materialize_grads(False)
+        return ml, z, kl, loss_t, z_q, ppl_t, idx
+
+    @staticmethod
+    def backward(ctx, g_ml, g_z, g_kl, g_loss, g_zq, _g_ppl, _g_idx):
+        ah, wcat, ml, epsc, wc, idx, z = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dml, colsum, dW = _rvq_backward(ml, epsc, wc, idx, z, ctx.cfg, g_z, g_kl, g_loss, g_zq, need[7], need[0] or need[1] or need[2],
+                                        need[2] and g_ml is None)
+        dah = dwcat = dbcat = None
+        if dml is not None:
+            if g_ml is not None:                      # a second loss on mu | logstd
+                dml = dml + g_ml
+                colsum = _colsum(dml) if need[2] else None
+            dbcat = colsum
+            dwcat = _weight_grad(ah, dml) if need[1] else None
+            dah = torch.mm(dml, wcat) if need[0] else None
+        return dah, dwcat, dbcat, None, None, None, None, dW, None
 
 
 def _reparam_vq(ml, eps, seed, training, vq):
@@ -722,8 +799,9 @@ def negative_sampling_raw(graph_or_pair, num_nodes, num, seed):
                                                _lib.stream()), "ceeg_neg_filter_build")
             pair.neg_filter = (bitmap, nbits)
         filt, bits = pair.neg_filter
-    _lib.check(L.ceeg_neg_sample_uniform_filtered(pair.rowptr.data_ptr(), pair.col.data_ptr(), int(num_nodes), int(num), int(seed), _lib.ptr(filt),
-                                                  bits, out[0].data_ptr(), out[1].data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform_filtered")
+    with _lib.timed("neg_sample"):
+        _lib.check(L.ceeg_neg_sample_uniform_filtered(pair.rowptr.data_ptr(), pair.col.data_ptr(), int(num_nodes), int(num), int(seed), _lib.ptr(filt),
+                                                      bits, out[0].data_ptr(), out[1].data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform_filtered")
     return out
 
 
@@ -892,6 +970,23 @@ class VariationalGCNEncoder(nn.Module):
         ml = self.forward_fused(x, graph)
         return ml[:, : self.latent], ml[:, self.latent:]
 
+    def encode_reparam_vq(self, x, graph, eps, seed, training, vq):
+        """(ml, z, kl, vq_loss, z_q, perplexity, idx): encoder -> reparametrise + KL -> VectorQuantizer (scripts/models.py:30-32).
+        When the first layer runs aggregate-first (in_channels < 2 * latent) the step is three autograd nodes -
+        A_hat x;  A_hat relu((A_hat x) W1^T + b1) with the ReLU mask in the transposed pass' epilogue;  head product +
+        reparametrise + quantiser with the head's bias gradient a real output of the fused backward - the same arithmetic
+        re-associated: (A_hat h) W^T + b == A_hat (h W^T) + b.  CEEG_FUSED_HEAD=0 keeps the layer-by-layer form (the checker)."""
+        D = self.latent
+        if (self.conv1.aggregate_first and D % 4 == 0 and os.environ.get("CEEG_FUSED_RVQ", "1") == "1"
+                and os.environ.get("CEEG_FUSED_HEAD", "1") == "1"):
+            ax = _GcnAggregate.apply(x, None, graph, False)
+            ah = _LinearReluAggregate.apply(ax, self.conv1.lin.weight, self.conv1.bias, graph)
+            wcat = torch.cat([self.conv_mu.lin.weight, self.conv_logstd.lin.weight], dim=0)
+            bcat = torch.cat([self.conv_mu.bias, self.conv_logstd.bias], dim=0)
+            return _HeadReparamVQ.apply(ah, wcat, bcat, eps, seed, training, False, vq.embedding.weight, vq.beta)
+        ml = self.forward_fused(x, graph)
+        return (ml,) + tuple(_reparam_vq(ml, eps, seed, training, vq))
+
 
 class VGAE(nn.Module):
     """PyG VGAE surface: encode / reparametrize / kl_loss / recon_loss / decoder."""
@@ -962,10 +1057,9 @@ class VGAEVQ(nn.Module):
 
     def forward(self, x, graph, step=0, eps=None, sigma=None, neg_edge_index=None):
         N = x.shape[0]
-        ml = self.encoder.forward_fused(x, graph)
         D = self.latent
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
-        z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, seed, self.training, self.vector_quantization)
+        ml, z, kl, vq_loss, z_q, ppl, idx = self.encoder.encode_reparam_vq(x, graph, eps, seed, self.training, self.vector_quantization)
         if self.negatives == "uniform" or neg_edge_index is not None:
             # literal path: recon_loss(z_q, pos_edge_index, negative_sampling(...)) - one fresh sample set per step
             if neg_edge_index is None:
@@ -1040,9 +1134,9 @@ class ConditionalVGAEVQ(nn.Module):
         if batch.shape[0] != N or condition.shape[1] != self.cond_channels:
             raise ValueError("batch must hold one graph id per node and condition must be [num_graphs, cond_channels]")
         cn = condition.index_select(0, batch)  # c[batch]
-        ml = self.encoder.forward_fused(torch.cat((x, cn), dim=1), graph)
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
-        z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, seed, self.training, self.vector_quantization)
+        ml, z, kl, vq_loss, z_q, ppl, idx = self.encoder.encode_reparam_vq(torch.cat((x, cn), dim=1), graph, eps, seed, self.training,
+                                                                          self.vector_quantization)
         mod = N if nodes_per_graph is None else int(nodes_per_graph)
         if N % mod:
             raise ValueError("nodes_per_graph must divide the number of nodes of the batch")

@@ -166,6 +166,15 @@ int ceeg_spmm_csr_items(const int32_t* rowptr, const int32_t* col, const float* 
                         int accumulate, float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items,
                         int64_t n_long, void* ws, size_t ws_bytes, void* stream);
 
+/* ceeg_spmm_csr_items whose finished rows pass a ReLU's backward mask: out[i,:] = (sum_p v(p) X[col[p],:]) * (mask[i,:] > 0).
+ * For dh = A_hat^T g followed by autograd's ReLU backward (h = relu(.) is the aggregated layer's input, scripts/run.py:96 via
+ * PyG GCNConv): the mask rides in the epilogue of the pass that produces dh - bitwise what ceeg_relu_bwd_colsum's gm is -
+ * instead of a separate read-modify-write of the [N, F] gradient.  mask: [N, ld_mask] fp32 (the ReLU's OUTPUT), 16-byte aligned. */
+int ceeg_spmm_csr_masked(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
+                         const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* mask, int64_t ld_mask,
+                         float* out, int64_t ldo, int64_t max_row_nnz, const int32_t* long_items, int64_t n_long,
+                         void* ws, size_t ws_bytes, void* stream);
+
 /* ceeg_spmm_csr whose gathered matrix is a TABLE read through a row index: out[i,:] (+)= sum_p v(p) * table[xidx[col[p]], :].
  * For a quantised latent (z[n] = codebook[code[n]] bit for bit) this is the same sum as gathering z itself - bitwise equal -
  * with the rows coming from a few hundred KB that stay in L2 (the backward of the edge-list decoder over sampled negatives). */

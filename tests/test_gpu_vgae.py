@@ -160,11 +160,16 @@ def _check_step_against_fp64_oracle(ref, model, loss, aux, args, kwargs):
     grads_close(model, ref)
 
 
-def test_full_step_vs_oracle():
-    """GCN-VGAE + VQ training step: loss, code indices and every parameter gradient vs the CPU restatement."""
+@pytest.mark.parametrize("Fi,D,fused_head", [(32, 16, "1"), (16, 16, "1"), (16, 16, "0"), (12, 64, "1")])
+def test_full_step_vs_oracle(Fi, D, fused_head, monkeypatch):
+    """GCN-VGAE + VQ training step: loss, code indices and every parameter gradient vs the CPU restatement.  Fi < 2 D runs the
+    first layer aggregate-first and the step as three fused autograd nodes (ReLU mask in the transposed aggregation's epilogue,
+    head bias gradient out of the fused reparam / VQ backward); CEEG_FUSED_HEAD=0 keeps the layer-by-layer form; Fi = 2 D is
+    the linear-first first layer."""
     from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
     from oracle import ref_torch
-    N, E, Fi, D, n_e = 4000, 64000, 32, 16, 64
+    monkeypatch.setenv("CEEG_FUSED_HEAD", fused_head)
+    N, E, n_e = 4000, 64000, 64
     ei_np = _graph(N, E, 2)
     torch.manual_seed(0)
     ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
@@ -674,7 +679,7 @@ def test_fused_reparam_vq_backward_equals_the_two_steps(N, D, n_e, with_eps, mon
     """ceeg_reparam_vq_bwd (dz of the quantiser never written, z recomputed, bias column sums in the same pass) gives the
     gradient of ceeg_vq_backward followed by ceeg_reparam_kl_bwd bit for bit; its column sums equal the gradient's."""
     from causal_eeg_vae_amd import VectorQuantizer
-    from causal_eeg_vae_amd.models import _reparam_vq, _take_colsum
+    from causal_eeg_vae_amd.models import _reparam_vq
     torch.manual_seed(N + D)
     ml0 = torch.randn(N, 2 * D, device="cuda")
     ml0[::5, D:] = 10.7   # clamped rows: zero logstd gradient
@@ -694,24 +699,34 @@ def test_fused_reparam_vq_backward_equals_the_two_steps(N, D, n_e, with_eps, mon
         outs.append((z.detach(), kl.detach(), vq_loss.detach(), z_q.detach(), idx, ml.grad.clone(), vq.embedding.weight.grad.clone()))
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
-    # the column sums offered to the encoder head's bias gradient
-    monkeypatch.setenv("CEEG_FUSED_RVQ", "1")
-    ml = ml0.clone().requires_grad_(True)
-    z, kl, vq_loss, z_q, ppl, idx = _reparam_vq(ml, eps, 1234, True, vq)
-    got = {}
-    def hook(g):
-        got["cs"] = _take_colsum(g)
-    ml.register_hook(hook)
+    # the head function: its bias gradient (the fused backward's column sums, a real output) equals the column sums of the
+    # gradient that reaches mu | logstd, and its other gradients those of the dense product in front of _reparam_vq
+    from causal_eeg_vae_amd.models import _HeadReparamVQ
+    ah = ml0.clone()                                            # ml = ah (I + small)^T + small: the clamped rows stay clamped
+    wcat = (torch.eye(2 * D, device="cuda") + 0.01 * torch.randn(2 * D, 2 * D, device="cuda")).requires_grad_(True)
+    bcat = (0.05 * torch.randn(2 * D, device="cuda")).requires_grad_(True)
+    ah_a = ah.clone().requires_grad_(True)
+    vq.embedding.weight.grad = None
+    ml, z, kl, vq_loss, z_q, ppl, idx = _HeadReparamVQ.apply(ah_a, wcat, bcat, eps, 1234, True, False, vq.embedding.weight, vq.beta)
     (1.3 * vq_loss + (z_q * r).sum() + 0.7 * kl).backward()
-    assert got["cs"] is not None
-    ref = ml.grad.double().sum(0)
-    np.testing.assert_allclose(got["cs"].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()) + 1e-30)
+    got = (ah_a.grad.clone(), wcat.grad.clone(), bcat.grad.clone(), vq.embedding.weight.grad.clone())
+    ah_b, w_b, b_b = ah.clone().requires_grad_(True), wcat.detach().clone().requires_grad_(True), bcat.detach().clone().requires_grad_(True)
+    vq.embedding.weight.grad = None
+    ml_b = torch.addmm(b_b, ah_b, w_b.t().contiguous())
+    ml_b.retain_grad()
+    z2, kl2, vq_loss2, z_q2, _, idx2 = _reparam_vq(ml_b, eps, 1234, True, vq)
+    (1.3 * vq_loss2 + (z_q2 * r).sum() + 0.7 * kl2).backward()
+    assert torch.equal(ml.detach(), ml_b.detach()) and torch.equal(idx, idx2)
+    ref = ml_b.grad.double().sum(0)
+    np.testing.assert_allclose(got[2].double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()) + 1e-30)
+    assert torch.equal(got[0], ah_b.grad) and torch.equal(got[3], vq.embedding.weight.grad)
+    np.testing.assert_allclose(got[1].cpu().numpy(), w_b.grad.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(w_b.grad.abs().max()))
 
 
 def test_head_bias_gradient_when_the_encoder_output_feeds_a_second_loss():
-    """aux['ml'] (the fused mu | logstd encoder output) also feeds the loss: autograd then ACCUMULATES a second gradient
-    into the tensor the fused reparam/VQ backward produced, and the column sums that kernel left for the head's bias
-    gradient no longer describe it.  The hint must be dropped (version check) and the bias gradients must still be exact."""
+    """aux['ml'] (the fused mu | logstd encoder output) also feeds the loss: a second gradient then arrives for that output of
+    the head function, is added to the fused reparam/VQ backward's result, and the column sums that kernel left no longer
+    describe the total - they are recomputed.  The bias gradients must still be exact."""
     from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
     from oracle import ref_torch
     N, E, Fi, D, n_e = 1500, 20000, 16, 16, 32
