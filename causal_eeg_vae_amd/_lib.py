@@ -57,6 +57,11 @@ SIGNATURES = {
     "ceeg_edge_bce_codes_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_edge_bce_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_int, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_spmm_csr_table": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_neg_sample_pair_bce_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _c_u64, _vp, _c_int, _vp, _vp, _vp, _vp,
+                                                    _vp, _vp, _c_sz, _vp]),
+    "ceeg_decoder_codes_bwd_pairs_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64]),
+    "ceeg_decoder_codes_bwd_pairs": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64,
+                                              _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_decoder_codes_chunk": (_c_int, []),
     "ceeg_decoder_codes_supported": (_c_int, [_c_int, _c_int]),
     "ceeg_decoder_codes_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int, _c_i64, _c_i64]),
@@ -65,6 +70,7 @@ SIGNATURES = {
     "ceeg_bias_relu": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _c_int, _vp]),
     "ceeg_colsum_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_relu_bwd_colsum": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),
+    "ceeg_recon_finish": (_c_int, [_vp, _vp, _vp, _c_f32, _vp, _vp]),
     "ceeg_colsum": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),
     "ceeg_gat_softmax_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f32, _vp, _vp]),
     "ceeg_gat_attn_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_f32, _vp, _vp, _vp]),

@@ -78,6 +78,52 @@ __device__ __forceinline__ float2 ceeg_box_muller(uint32_t x0, uint32_t x1) {
   return make_float2(r * c, r * s);
 }
 
+__device__ __forceinline__ bool csr_has(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t d, int32_t s) {
+  int lo = rowptr[d];
+  const int end = rowptr[d + 1];
+  int hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (col[mid] < s) lo = mid + 1; else hi = mid;
+  }
+  return lo < end && col[lo] == s;
+}
+
+// Edge-set prefilter of the sampler: one bit per hash bucket of (src, dst); a clear bit proves "not an edge" with ONE random
+// read instead of the row-pointer pair and the binary search (exact: set bits still go through the search).
+__device__ __forceinline__ uint32_t neg_filter_hash(int32_t s, int32_t d, unsigned bits) {
+  const uint64_t x = (((uint64_t)(uint32_t)d << 32) | (uint64_t)(uint32_t)s) * 0x9E3779B97F4A7C15ull;
+  return (uint32_t)(x >> (64 - bits));
+}
+
+// The k-th uniform negative sample (include/ceeg.h, ceeg_neg_sample_uniform; restated in oracle/ceeg_oracle.c): up to 16 Philox
+// candidates, rejected when src == dst or src -> dst is an edge; (-1, -1) when all collide.  One definition for the stand-alone
+// sampler (graph.hip) and the sampler fused into the pair-list forward (decoder_codes.hip): the samples are the same bit for bit.
+template <bool FILTER>
+__device__ __forceinline__ void ceeg_neg_draw(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, uint64_t seed,
+                                              int64_t k, const uint32_t* __restrict__ filter, unsigned filter_bits, int32_t& s, int32_t& d) {
+  s = -1;
+  d = -1;
+  for (uint32_t a = 0; a < 16; ++a) {  // bounded: every lane leaves after at most 16 attempts
+    const uint4 x = ceeg_philox(seed, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), CEEG_TAG_NEG, a);
+    const int32_t cs = (int32_t)(((uint64_t)x.x * (uint64_t)N) >> 32);
+    const int32_t cd = (int32_t)(((uint64_t)x.y * (uint64_t)N) >> 32);
+    if (cs == cd) continue;
+    if (FILTER) {
+      const uint32_t h = neg_filter_hash(cs, cd, filter_bits);
+      if (((filter[h >> 5] >> (h & 31)) & 1u) == 0u) {  // clear bit: not an edge
+        s = cs;
+        d = cd;
+        break;
+      }
+    }
+    if (csr_has(rowptr, col, cd, cs)) continue;
+    s = cs;
+    d = cd;
+    break;
+  }
+}
+
 // ---------------------------------------------------------------- internal cross-file launchers
 // Extra addressing for the SpMM used by the fused decoder backward: affine (bijective) maps on the
 // gathered column index and on the output row, and a device-side scale applied to the row sum.

@@ -46,11 +46,20 @@ struct DcGradArgs {
   float* coef_sum;   // [N] or NULL: summed, scaled coefficients of every node's pairs (conditional decoders)
   float* cpart_csr;  // [chunk*2+slot][2]: (sum cp, sum cn) of the pieces of long CSR rows
   float* cpart_t;    // [chunk*2+slot][2]: the same for long transposed rows
+  // PAIRS: a fourth list per node - the node-sorted incidence keys of an arbitrary pair list (ceeg_pair_bce_codes_fwd),
+  // node n's keys at [p_rowptr[n], p_rowptr[n+1]); coefficient of key k = p_C[code[n] * K + (k & 1023)]; scaled by gscale[1]
+  const int32_t* p_rowptr;
+  const uint32_t* p_keys;
+  const int32_t* p_code;
+  const float* p_C;
 };
 
 struct DcNode {  // one pipeline stage of dc_grad_rows_kernel: a node's three lists and their first batches
   int A_lo, A_hi, a_hi, B_lo, B_hi, b_hi, C_lo, C_hi, c_hi, tp;
   uint4 ra, rb, rc;
+  int P_lo, P_hi, kself;  // PAIRS: the node's incidence keys, its own code, the first two batches of keys and coefficients
+  unsigned k0, k1;
+  float c0, c1;
 };
 
 template <int T>
@@ -361,8 +370,11 @@ __device__ __forceinline__ float dc_piece_sums(const float* __restrict__ part, i
 // slab's counter (integer atomics only: which wave computes a node does not change the node's result).
 // NEG = false: positives only (every cn is 0): the sigma-row list and the cn halves of the transposed list are not walked.
 // CSUM: the workgroups of slab 0 also write a.coef_sum.
-template <bool NEG, bool CSUM>
+// PAIRS (with NEG = false): the sampled-pair list of the literal recon_loss is a fourth list of every node - its sum lands in
+// the accumulator the structured negatives would use and is scaled by gscale[1] - so both pair sets leave ONE dz write.
+template <bool NEG, bool CSUM, bool PAIRS = false>
 __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArgs a) {
+  static_assert(!(NEG && PAIRS), "the pair list takes the structured negatives' accumulator");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float4* lds4 = reinterpret_cast<float4*>(smem);
   const int nslab = a.D / DC_CW;
@@ -391,6 +403,12 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       clo = a.t_rowptr[n];
       chi = a.t_rowptr[n + 1];
     }
+    int plo = 0, phi = 0, pks = 0;
+    if (PAIRS && n < a.N) {
+      plo = a.p_rowptr[n];
+      phi = a.p_rowptr[n + 1];
+      pks = dc_clamp_code(a.p_code[n], a.K);
+    }
     const int cnt = a.N - base_n < 64 ? (int)(a.N - base_n) : 64;
     // Three-stage pipeline over the draw's iterations (4 nodes each): while iteration `it` computes, the records of
     // it+1 are in flight (their t_perm entries were fetched an iteration earlier) and the t_perm entries of it+2 are issued.
@@ -407,12 +425,27 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
       s.c_hi = s.C_hi - s.C_lo > DC_CHUNK ? s.C_lo : s.C_hi;
       s.tp = 0;
       if (s.C_lo + gl < s.c_hi) s.tp = a.t_perm[s.C_lo + gl];
+      if (PAIRS) {
+        s.P_lo = __shfl(plo, j, 64);
+        s.P_hi = __shfl(phi, j, 64);
+        s.kself = __shfl(pks, j, 64);
+        if (!ok) s.P_hi = s.P_lo;
+        s.k0 = 0u; s.k1 = 0u;
+        if (s.P_lo + gl < s.P_hi) s.k0 = a.p_keys[s.P_lo + gl];
+        if (s.P_lo + 16 + gl < s.P_hi) s.k1 = a.p_keys[s.P_lo + 16 + gl];
+      }
     };
     auto records = [&](DcNode& s) {  // first batches of the three lists
       s.ra = zero4; s.rb = zero4; s.rc = zero4;
       if (s.C_lo + gl < s.c_hi) s.rc = a.rec[s.tp];
       if (s.A_lo + gl < s.a_hi) s.ra = a.rec[s.A_lo + gl];
       if (NEG && s.B_lo + gl < s.b_hi) s.rb = a.rec[s.B_lo + gl];
+      if (PAIRS) {
+        const float* row = a.p_C + (size_t)s.kself * a.K;
+        s.c0 = 0.f; s.c1 = 0.f;
+        if (s.P_lo + gl < s.P_hi) s.c0 = row[s.k0 & 1023u];
+        if (s.P_lo + 16 + gl < s.P_hi) s.c1 = row[s.k1 & 1023u];
+      }
     };
     bounds(0, s0);
     bounds(1, s1);
@@ -437,6 +470,22 @@ __global__ __launch_bounds__(DC_GRAD_THREADS) void dc_grad_rows_kernel(DcGradArg
         const int nb = s0.b_hi - base;
         if (CSUM) cs_n += __uint_as_float(rb.y);
         dc_batch1(lds4, gl, __uint_as_float(rb.y), (int)rb.w, nb < 0 ? 0 : nb, s3v);
+      }
+      if (PAIRS) {  // the node's sampled-pair incidences, in sorted (= incidence) order: sum_k C[code n][code_k] W[code_k]
+        const int len = s0.P_hi - s0.P_lo;
+        dc_batch1(lds4, gl, s0.c0, (int)(s0.k0 & 1023u), len < 0 ? 0 : len, s3v);
+        dc_batch1(lds4, gl, s0.c1, (int)(s0.k1 & 1023u), len - 16 < 0 ? 0 : len - 16, s3v);
+        const float* row = a.p_C + (size_t)s0.kself * a.K;
+        for (int base = s0.P_lo + 32; __any(base < s0.P_hi); base += 16) {  // lists longer than 32: fetched in place
+          unsigned k = 0u;
+          float c = 0.f;
+          if (base + gl < s0.P_hi) {
+            k = a.p_keys[base + gl];
+            c = row[k & 1023u];
+          }
+          const int nb = s0.P_hi - base;
+          dc_batch1(lds4, gl, c, (int)(k & 1023u), nb < 0 ? 0 : nb, s3v);
+        }
       }
       // (2) + (4) n as source: sum_q cp W[kr], sum_q cn W[ksr] over the transposed row
       for (int base = s0.C_lo; __any(base < s0.c_hi); base += 16) {
@@ -640,16 +689,42 @@ extern "C" int ceeg_edge_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int
   return CEEG_OK;
 }
 
+namespace {
+struct DcPairList {  // node-sorted incidence keys of a pair list (NULL p_rowptr: none)
+  const int32_t* p_rowptr = nullptr;
+  const uint32_t* p_keys = nullptr;
+  const int32_t* p_code = nullptr;
+  const float* p_C = nullptr;
+};
+int dc_decoder_bwd_impl(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                        const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                        int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
+                        int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
+                        float* dz, int64_t lddz, float* coef_sum, void* ws, size_t ws_bytes, void* stream, const DcPairList& pl);
+}  // namespace
+
 extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
                                       const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
                                       int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
                                       int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
                                       float* dz, int64_t lddz, float* coef_sum, void* ws, size_t ws_bytes, void* stream) {
+  return dc_decoder_bwd_impl(W, ldw, n_e, D, rowptr, t_rowptr, t_perm, N, nnz, sig_a, sig_b, sig_ainv, sig_mod, long_items, n_long,
+                             t_long_items, n_tlong, max_row_nnz, max_trow_nnz, rec, gscale, dz, lddz, coef_sum, ws, ws_bytes, stream,
+                             DcPairList());
+}
+
+namespace {
+int dc_decoder_bwd_impl(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                        const int32_t* t_perm, int64_t N, int64_t nnz, int64_t sig_a, int64_t sig_b, int64_t sig_ainv,
+                        int64_t sig_mod, const int32_t* long_items, int64_t n_long, const int32_t* t_long_items,
+                        int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz, const void* rec, const float* gscale,
+                        float* dz, int64_t lddz, float* coef_sum, void* ws, size_t ws_bytes, void* stream, const DcPairList& pl) {
   if (!W || !rowptr || !t_rowptr || !gscale || !dz || N <= 0 || nnz < 0 || (nnz > 0 && (!t_perm || !rec))) return CEEG_EINVAL;
   if (!dc_supported(n_e, D) || N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || lddz < D || (lddz % 4) != 0 || !ceeg_aligned(W, 16) || !ceeg_aligned(dz, 16) || (rec && !ceeg_aligned(rec, 16)))
     return CEEG_EINVAL;
   const bool no_neg = sig_a == 0;  // positives only, as ceeg_decoder_codes_fwd: sigma is then the identity
+  if (pl.p_rowptr && (!no_neg || coef_sum || !pl.p_code || !pl.p_C)) return CEEG_EINVAL;  // a pair list rides with the positives-only form
   if (no_neg) { sig_a = 1; sig_b = 0; sig_ainv = 1; }
   if (sig_mod <= 0 || (N % sig_mod) != 0 || sig_a <= 0 || sig_b < 0 || sig_b >= sig_mod || sig_ainv <= 0) return CEEG_EINVAL;
   if ((uint64_t)((unsigned __int128)(uint64_t)sig_a * (uint64_t)sig_ainv % (uint64_t)sig_mod) != (uint64_t)(1 % sig_mod)) return CEEG_EINVAL;
@@ -671,6 +746,7 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
   a.cpart_csr = reinterpret_cast<float*>(reinterpret_cast<char*>(a.part_t) + dc_part_bytes(nnz, D, n_tlong));
   a.cpart_t = reinterpret_cast<float*>(reinterpret_cast<char*>(a.cpart_csr) + dc_cpart_bytes(nnz, n_long));
   a.coef_sum = coef_sum;
+  a.p_rowptr = pl.p_rowptr; a.p_keys = pl.p_keys; a.p_code = pl.p_code; a.p_C = pl.p_C;
   if (hipMemsetAsync(ws, 0, 1024, st) != hipSuccess) return CEEG_ELAUNCH;
   const int nslab = D / DC_CW;
   const size_t lds = (size_t)n_e * DC_CW * 4;
@@ -704,13 +780,15 @@ extern "C" int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int 
     }
   }
   const dim3 grid(grid_for(N)), block(DC_GRAD_THREADS);
-  if (no_neg && coef_sum) hipLaunchKernelGGL((dc_grad_rows_kernel<false, true>), grid, block, lds, st, a);
+  if (pl.p_rowptr) hipLaunchKernelGGL((dc_grad_rows_kernel<false, false, true>), grid, block, lds, st, a);
+  else if (no_neg && coef_sum) hipLaunchKernelGGL((dc_grad_rows_kernel<false, true>), grid, block, lds, st, a);
   else if (no_neg) hipLaunchKernelGGL((dc_grad_rows_kernel<false, false>), grid, block, lds, st, a);
   else if (coef_sum) hipLaunchKernelGGL((dc_grad_rows_kernel<true, true>), grid, block, lds, st, a);
   else hipLaunchKernelGGL((dc_grad_rows_kernel<true, false>), grid, block, lds, st, a);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
+}  // namespace
 
 // ================================================================================================ pair lists on a quantised latent
 // recon_loss over an ARBITRARY pair list (the negatives `negative_sampling` draws afresh every step) without building a CSR pair.
@@ -766,6 +844,50 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
     const int ni = __builtin_nontemporal_load(ei + e), nj = __builtin_nontemporal_load(ej + e);  // streams: leave L2 to code[] and T
     unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
     if (ni >= 0 && nj >= 0 && ni < N && nj < N) {
+      ki = (unsigned)dc_clamp_code(code[ni], K);
+      kj = (unsigned)dc_clamp_code(code[nj], K);
+      acc += T[(size_t)ki * K + kj];
+      cnt += 1.0f;
+      key_i = (unsigned)ni;
+      key_j = (unsigned)nj;
+    }
+    if (keys) {
+      __builtin_nontemporal_store((key_j << DC_PAIR_NODE_SHIFT) | ki, &keys[e].x);
+      __builtin_nontemporal_store((key_i << DC_PAIR_NODE_SHIFT) | kj, &keys[e].y);
+    }
+  }
+  acc = ceeg_wave_sum(acc);
+  cnt = ceeg_wave_sum(cnt);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { red[0][wave] = acc; red[1][wave] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = part + (size_t)blockIdx.x * 3;
+    o[0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    o[1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    o[2] = 0.f;
+  }
+}
+
+// negative_sampling fused into the pair-list forward: thread e DRAWS pair e (ceeg_neg_draw: the stand-alone sampler's samples bit
+// for bit), writes it out (the caller's neg_edge_index) and goes on as dc_pair_fwd_kernel does - same grid, same per-thread
+// strides, same partial layout, so loss and keys equal the two-launch form exactly.  The 128 MB pair list is never re-read.
+template <bool FILTER>
+__global__ __launch_bounds__(256) void dc_sample_pair_fwd_kernel(const float* __restrict__ T, int K, const int32_t* __restrict__ code,
+                                                                 const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                 int64_t N, int64_t E, uint64_t seed, const uint32_t* __restrict__ filter,
+                                                                 unsigned filter_bits, int32_t* __restrict__ neg_src,
+                                                                 int32_t* __restrict__ neg_dst, uint2* __restrict__ keys,
+                                                                 float* __restrict__ part) {
+  __shared__ float red[2][4];
+  float acc = 0.f, cnt = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    int32_t ni, nj;
+    ceeg_neg_draw<FILTER>(rowptr, col, N, seed, e, filter, filter_bits, ni, nj);
+    __builtin_nontemporal_store(ni, neg_src + e);
+    __builtin_nontemporal_store(nj, neg_dst + e);
+    unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
+    if (ni >= 0 && nj >= 0) {
       ki = (unsigned)dc_clamp_code(code[ni], K);
       kj = (unsigned)dc_clamp_code(code[nj], K);
       acc += T[(size_t)ki * K + kj];
@@ -1001,4 +1123,78 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
   hipLaunchKernelGGL(dc_pair_grad_kernel, dim3((unsigned)(per_slab * nslab)), dim3(DC_GRAD_THREADS), (size_t)n_e * DC_CW * 4, st, a);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
+}
+
+// negative_sampling + the pair-list forward in one launch (see dc_sample_pair_fwd_kernel).
+extern "C" int ceeg_neg_sample_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
+                                                  const int32_t* col, int64_t N, int64_t num, uint64_t seed, const uint32_t* filter,
+                                                  int filter_bits, int32_t* neg_src, int32_t* neg_dst, uint32_t* keys, float* coef_table,
+                                                  float* loss_sum, void* ws, size_t ws_bytes, void* stream) {
+  if (!W || !code || !rowptr || !col || !loss_sum || !coef_table || num < 0 || N <= 1 || (num > 0 && (!neg_src || !neg_dst))) return CEEG_EINVAL;
+  if (filter && (filter_bits < 13 || filter_bits > 32)) return CEEG_EINVAL;
+  if (!dc_pair_supported(n_e, D, N, num)) return CEEG_EUNSUPPORTED;
+  if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && !ceeg_aligned(keys, 8)) || !ceeg_aligned(coef_table, 4)) return CEEG_EINVAL;
+  if (ws_bytes < dc_pair_fwd_bytes(n_e) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t kk = ceeg_ws_part((size_t)n_e * n_e, 4);
+  float* G = static_cast<float*>(ws);
+  float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + kk);
+  float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * kk);
+  hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dc_pair_tables_kernel, dim3((unsigned)((n_e * n_e + 255) / 256)), dim3(256), 0, st, G, n_e, 1, T, coef_table);
+  CEEG_CHECK_LAUNCH();
+  int64_t nb = (num + 255) / 256;
+  nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
+  if (filter)
+    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, rowptr, col, N, num, seed, filter,
+                       (unsigned)filter_bits, neg_src, neg_dst, reinterpret_cast<uint2*>(keys), part);
+  else
+    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, rowptr, col, N, num, seed, filter,
+                       0u, neg_src, neg_dst, reinterpret_cast<uint2*>(keys), part);
+  CEEG_CHECK_LAUNCH();
+  float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
+  hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
+  CEEG_CHECK_LAUNCH();
+  if (hipMemcpyAsync(loss_sum, tmp, 2 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) return CEEG_ELAUNCH;
+  return CEEG_OK;
+}
+
+// Backward of BOTH pair sets of the literal recon_loss in one gradient kernel: the positives' three lists (ceeg_decoder_codes_bwd with
+// sig_a = 0) and the sampled pairs' node-sorted incidence keys as a fourth list; dz is written once.
+extern "C" size_t ceeg_decoder_codes_bwd_pairs_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong, int64_t E) {
+  const size_t a = ceeg_decoder_codes_ws_bytes(N, nnz, n_e, D, n_long, n_tlong);
+  const size_t b = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
+  if (a == 0 || b == 0) return 0;
+  return ceeg_align_up(a, 256) + b;
+}
+
+extern "C" int ceeg_decoder_codes_bwd_pairs(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                                            const int32_t* t_perm, int64_t N, int64_t nnz, const int32_t* long_items, int64_t n_long,
+                                            const int32_t* t_long_items, int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz,
+                                            const void* rec, const int32_t* code, const uint32_t* keys, const float* coef_table, int64_t E,
+                                            const float* gscale, float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream) {
+  if (!code || !coef_table || E < 0 || (E > 0 && !keys) || N <= 0) return CEEG_EINVAL;
+  if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
+  const size_t need_a = ceeg_align_up(ceeg_decoder_codes_ws_bytes(N, nnz, n_e, D, n_long, n_tlong), 256);
+  const size_t need_b = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
+  if (need_a == 0 || need_b == 0 || ws_bytes < need_a + need_b || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  DcPairWs w;
+  if (dc_pair_bwd_layout(E, N, static_cast<char*>(ws) + need_a, ws_bytes - need_a, &w) == 0) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t M = 2 * E;
+  if (M > 0) {
+    size_t tb = w.temp_bytes;
+    if (rocprim::radix_sort_keys(w.temp, tb, keys, w.keys_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
+                                 (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
+      return CEEG_ELAUNCH;
+    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
+    CEEG_CHECK_LAUNCH();
+  } else if (hipMemsetAsync(w.rowptr, 0, ((size_t)N + 1) * 4, st) != hipSuccess) {
+    return CEEG_ELAUNCH;
+  }
+  DcPairList pl;
+  pl.p_rowptr = w.rowptr; pl.p_keys = w.keys_out; pl.p_code = code; pl.p_C = coef_table;
+  return dc_decoder_bwd_impl(W, ldw, n_e, D, rowptr, t_rowptr, t_perm, N, nnz, 0, 0, 1, N, long_items, n_long, t_long_items, n_tlong,
+                             max_row_nnz, max_trow_nnz, rec, gscale, dz, lddz, nullptr, ws, need_a, stream, pl);
 }

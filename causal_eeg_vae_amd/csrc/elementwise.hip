@@ -142,3 +142,28 @@ extern "C" int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y,
 extern "C" int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, void* ws, size_t ws_bytes, void* stream) {
   return colsum_launch(g, ldg, nullptr, 0, nullptr, 0, N, F, colsum, ws, ws_bytes, static_cast<hipStream_t>(stream));
 }
+
+// recon_loss's last step (upstream PyG GAE.recon_loss: pos_loss.mean() + neg_loss.mean()) as ONE tiny launch instead of a chain
+// of torch scalar kernels: out = { pos_sum / pos_count + neg_sum / max(neg_count, 1), 1 / pos_count, 1 / max(neg_count, 1),
+// pos_sum, neg_sum, neg_count }.  The two reciprocals are what the decoders' backward scales its coefficient sums with.
+namespace {
+__global__ void recon_finish_kernel(const float* __restrict__ pos_sum, const float* __restrict__ neg_sum, const float* __restrict__ neg_cnt,
+                                    float pos_count, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float ps = pos_sum[0], ns = neg_sum[0], nc = neg_cnt[0];
+  const float ip = 1.0f / pos_count, in = 1.0f / fmaxf(nc, 1.0f);
+  out[0] = ps * ip + ns * in;
+  out[1] = ip;
+  out[2] = in;
+  out[3] = ps;
+  out[4] = ns;
+  out[5] = nc;
+}
+}  // namespace
+
+extern "C" int ceeg_recon_finish(const float* pos_sum, const float* neg_sum, const float* neg_count, float pos_count, float* out, void* stream) {
+  if (!pos_sum || !neg_sum || !neg_count || !out || !(pos_count > 0.f)) return CEEG_EINVAL;
+  hipLaunchKernelGGL(recon_finish_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), pos_sum, neg_sum, neg_count, pos_count, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}

@@ -111,23 +111,6 @@ __global__ void gcn_val_kernel(const int32_t* __restrict__ rowptr, const int32_t
   }
 }
 
-__device__ __forceinline__ bool csr_has(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int32_t d, int32_t s) {
-  int lo = rowptr[d];
-  const int end = rowptr[d + 1];
-  int hi = end;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (col[mid] < s) lo = mid + 1; else hi = mid;
-  }
-  return lo < end && col[lo] == s;
-}
-
-// Edge-set prefilter of the sampler: one bit per hash bucket of (src, dst); a clear bit proves "not an edge" with ONE random
-// read instead of the row-pointer pair and the binary search (exact: set bits still go through the search).
-__device__ __forceinline__ uint32_t neg_filter_hash(int32_t s, int32_t d, unsigned bits) {
-  const uint64_t x = (((uint64_t)(uint32_t)d << 32) | (uint64_t)(uint32_t)s) * 0x9E3779B97F4A7C15ull;
-  return (uint32_t)(x >> (64 - bits));
-}
 __global__ void neg_filter_build_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N, unsigned bits,
                                         uint32_t* __restrict__ filter) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per row
@@ -146,25 +129,8 @@ __global__ void neg_sample_uniform_kernel(const int32_t* __restrict__ rowptr, co
                                           int32_t* __restrict__ neg_src, int32_t* __restrict__ neg_dst) {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= num) return;
-  int32_t s = -1, d = -1;
-  for (uint32_t a = 0; a < 16; ++a) {  // bounded: every lane leaves after at most 16 attempts
-    const uint4 x = ceeg_philox(seed, (uint32_t)k, (uint32_t)((uint64_t)k >> 32), CEEG_TAG_NEG, a);
-    const int32_t cs = (int32_t)(((uint64_t)x.x * (uint64_t)N) >> 32);
-    const int32_t cd = (int32_t)(((uint64_t)x.y * (uint64_t)N) >> 32);
-    if (cs == cd) continue;
-    if (FILTER) {
-      const uint32_t h = neg_filter_hash(cs, cd, filter_bits);
-      if (((filter[h >> 5] >> (h & 31)) & 1u) == 0u) {  // clear bit: not an edge
-        s = cs;
-        d = cd;
-        break;
-      }
-    }
-    if (csr_has(rowptr, col, cd, cs)) continue;
-    s = cs;
-    d = cd;
-    break;
-  }
+  int32_t s, d;
+  ceeg_neg_draw<FILTER>(rowptr, col, N, seed, k, filter, filter_bits, s, d);
   neg_src[k] = s;
   neg_dst[k] = d;
 }

@@ -687,11 +687,29 @@ class _PairBCECodes(torch.autograd.Function):
         return dz, None, None, None, None
 
 
+def _neg_filter(pair):
+    """(bitmap, bits) of the sampler's edge-set prefilter, built on first use and kept with the CSR pair; (None, 0) when
+    CEEG_NEG_FILTER=0 (the plain search: the checker form of the tests)."""
+    if os.environ.get("CEEG_NEG_FILTER", "1") != "1":
+        return None, 0
+    if getattr(pair, "neg_filter", None) is None:
+        L = _lib.lib()
+        nbits = int(L.ceeg_neg_filter_bits(pair.nnz))
+        bitmap = torch.empty((1 << nbits) // 32, dtype=torch.int32, device=pair.device)
+        _lib.check(L.ceeg_neg_filter_build(pair.rowptr.data_ptr(), pair.col.data_ptr(), pair.num_nodes, nbits, bitmap.data_ptr(),
+                                           _lib.stream()), "ceeg_neg_filter_build")
+        pair.neg_filter = (bitmap, nbits)
+    return pair.neg_filter
+
+
 class _UniformRecon(torch.autograd.Function):
     """recon_loss(z_q, pos_edge_index, neg_edge_index) of the literal sampler path in ONE autograd node, code form throughout:
-    positives through ceeg_decoder_codes_fwd/_bwd with the structured negatives off (sig_a = 0), the sampled pairs through
-    ceeg_pair_bce_codes_fwd/_bwd - whose gradient is ACCUMULATED into the positives' dz (no second [N, D] tensor, no add).
-    Returns (pos_mean + neg_sum / neg_count, [pos_sum, neg_sum, neg_count])."""
+    positives through ceeg_decoder_codes_fwd with the structured negatives off (sig_a = 0), the sampled pairs through
+    ceeg_pair_bce_codes_fwd - or, when the pairs are to be drawn here (neg_edge_index None, `seed` given), through
+    ceeg_neg_sample_pair_bce_codes_fwd, which draws pair k inside the kernel (same samples bit for bit) - and ONE gradient kernel for
+    both pair sets (ceeg_decoder_codes_bwd_pairs: the sampled pairs' node-sorted incidences are a fourth list of every node).
+    CEEG_PAIR_MERGED=0 keeps the two-launch forms (separate sampler; second gradient kernel accumulating into dz): bitwise equal.
+    Returns (pos_mean + neg_sum / neg_count, [pos_sum, neg_sum, neg_count], neg_edge_index int32 [2, E])."""
 
     @staticmethod
     def supported(table, num_nodes, num_pairs):
@@ -700,7 +718,7 @@ class _UniformRecon(torch.autograd.Function):
                 and L.ceeg_pair_bce_codes_supported(int(table.shape[0]), int(table.shape[1]), int(num_nodes), int(num_pairs)) == 1)
 
     @staticmethod
-    def forward(ctx, z, graph, neg_edge_index, table, table_idx):
+    def forward(ctx, z, graph, neg_edge_index, table, table_idx, seed=None, num_neg=None):
         _lib.require_cuda(z, neg_edge_index)
         L = _lib.lib()
         N, D = z.shape
@@ -708,6 +726,7 @@ class _UniformRecon(torch.autograd.Function):
         K = W.shape[0]
         p = graph.dec
         dev = z.device
+        merged = os.environ.get("CEEG_PAIR_MERGED", "1") == "1"
         li, lt = p.long_items(False), p.long_items(True)
         nl = 0 if li is None else li.shape[0]
         rec = torch.empty(max(p.nnz, 1), 4, dtype=torch.int32, device=dev)
@@ -717,36 +736,58 @@ class _UniformRecon(torch.autograd.Function):
             _lib.check(L.ceeg_decoder_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), p.rowptr.data_ptr(), p.col.data_ptr(), N, p.nnz,
                                                 0, 0, N, _lib.ptr(li), nl, p.max_row, None, rec.data_ptr(), psums.data_ptr(), ws.data_ptr(),
                                                 ws.numel(), _lib.stream()), "ceeg_decoder_codes_fwd")
-        i, j = _edge_lists_i32(neg_edge_index)
-        E = i.shape[0]
+        if neg_edge_index is None and not merged:
+            neg_edge_index = negative_sampling_raw(graph, N, int(num_neg), seed)
+        E = int(num_neg) if neg_edge_index is None else int(neg_edge_index.shape[1])
         want = ctx.needs_input_grad[0]
         nkeys = torch.empty(max(2 * E, 2), dtype=torch.int32, device=dev) if want else None
         ctab = torch.empty(K * K, dtype=torch.float32, device=dev)
         nout = torch.zeros(2, dtype=torch.float32, device=dev)
         ws = _lib.workspace(L.ceeg_pair_bce_codes_ws_bytes(E, N, K), dev)
-        with _lib.timed("pair_bce_fwd"):
-            _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N, 1,
-                                                 _lib.ptr(nkeys), ctab.data_ptr(), nout.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
-                       "ceeg_pair_bce_codes_fwd")
-        inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=dev), 1.0 / nout[1].clamp(min=1.0)])
-        sums = torch.stack([psums[0], nout[0], nout[1]])
+        if neg_edge_index is None:   # draw the pairs inside the forward kernel
+            neg_edge_index = torch.empty(2, max(E, 1), dtype=torch.int32, device=dev)[:, :E]
+            filt, bits = _neg_filter(p)
+            with _lib.timed("pair_bce_fwd"):
+                _lib.check(L.ceeg_neg_sample_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), p.rowptr.data_ptr(), p.col.data_ptr(),
+                                                                N, E, int(seed), _lib.ptr(filt), bits, neg_edge_index[0].data_ptr(),
+                                                                neg_edge_index[1].data_ptr(), _lib.ptr(nkeys), ctab.data_ptr(), nout.data_ptr(),
+                                                                ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_neg_sample_pair_bce_codes_fwd")
+        else:
+            i, j = _edge_lists_i32(neg_edge_index)
+            with _lib.timed("pair_bce_fwd"):
+                _lib.check(L.ceeg_pair_bce_codes_fwd(W.data_ptr(), W.stride(0), K, D, code.data_ptr(), i.data_ptr(), j.data_ptr(), E, N, 1,
+                                                     _lib.ptr(nkeys), ctab.data_ptr(), nout.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                           "ceeg_pair_bce_codes_fwd")
+        out = torch.empty(6, dtype=torch.float32, device=dev)   # rec, 1/E_pos, 1/pairs counted, pos_sum, neg_sum, neg_count
+        _lib.check(L.ceeg_recon_finish(psums.data_ptr(), nout.data_ptr(), nout[1:].data_ptr(), float(max(p.nnz, 1)), out.data_ptr(),
+                                       _lib.stream()), "ceeg_recon_finish")
         if want:
-            ctx.save_for_backward(W, rec, nkeys, ctab, code, inv)
-        ctx.graph, ctx.items, ctx.shape, ctx.E = graph, (li, lt), (N, D), E
-        ctx.mark_non_differentiable(sums)
-        return psums[0] * inv[0] + nout[0] * inv[1], sums
+            ctx.save_for_backward(W, rec, nkeys, ctab, code, out)
+        ctx.graph, ctx.items, ctx.shape, ctx.E, ctx.merged = graph, (li, lt), (N, D), E, merged
+        sums = out[3:6]
+        ctx.mark_non_differentiable(sums, neg_edge_index)
+        return out[0], sums, neg_edge_index
 
     @staticmethod
-    def backward(ctx, g, _gs):
-        W, rec, nkeys, ctab, code, inv = ctx.saved_tensors
+    def backward(ctx, g, _gs, _gn):
+        W, rec, nkeys, ctab, code, out = ctx.saved_tensors
         L = _lib.lib()
         N, D = ctx.shape
         K = W.shape[0]
         p = ctx.graph.dec
         li, lt = ctx.items
         nl, nt = (0 if li is None else li.shape[0]), (0 if lt is None else lt.shape[0])
-        gscale = (inv * g).contiguous()                      # [g / E_pos, g / pairs counted]
+        gscale = (out[1:3] * g).contiguous()                 # [g / E_pos, g / pairs counted]
         dz = torch.empty(N, D, dtype=torch.float32, device=W.device)
+        if ctx.merged:
+            ws = _lib.workspace(L.ceeg_decoder_codes_bwd_pairs_ws_bytes(N, p.nnz, K, D, nl, nt, ctx.E), W.device)
+            with _lib.timed("decoder_bwd"):
+                _lib.check(L.ceeg_decoder_codes_bwd_pairs(W.data_ptr(), W.stride(0), K, D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(),
+                                                          p.t_perm.data_ptr(), N, p.nnz, _lib.ptr(li), nl, _lib.ptr(lt), nt, p.max_row, p.max_trow,
+                                                          rec.data_ptr(), code.data_ptr(), nkeys.data_ptr(), ctab.data_ptr(), ctx.E,
+                                                          gscale.data_ptr(), dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
+                           "ceeg_decoder_codes_bwd_pairs")
+            return dz, None, None, None, None, None, None
         ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, K, D, nl, nt), W.device)
         with _lib.timed("decoder_bwd"):
             _lib.check(L.ceeg_decoder_codes_bwd(W.data_ptr(), W.stride(0), K, D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(), p.t_perm.data_ptr(),
@@ -759,7 +800,7 @@ class _UniformRecon(torch.autograd.Function):
                                                  gscale[1:].data_ptr(), 1,
                                                  dz.data_ptr(), dz.stride(0), ws.data_ptr(), ws.numel(), _lib.stream()),
                        "ceeg_pair_bce_codes_bwd")
-        return dz, None, None, None, None
+        return dz, None, None, None, None, None, None
 
 
 class InnerProductDecoder(nn.Module):
@@ -790,15 +831,7 @@ def negative_sampling_raw(graph_or_pair, num_nodes, num, seed):
     L = _lib.lib()
     pair = graph_or_pair.dec if isinstance(graph_or_pair, EventGraph) else graph_or_pair
     out = torch.empty(2, max(int(num), 1), dtype=torch.int32, device=pair.device)[:, : int(num)]
-    filt, bits = None, 0
-    if os.environ.get("CEEG_NEG_FILTER", "1") == "1":   # "0": the plain search (the checker form of the tests)
-        if getattr(pair, "neg_filter", None) is None:
-            nbits = int(L.ceeg_neg_filter_bits(pair.nnz))
-            bitmap = torch.empty((1 << nbits) // 32, dtype=torch.int32, device=pair.device)
-            _lib.check(L.ceeg_neg_filter_build(pair.rowptr.data_ptr(), pair.col.data_ptr(), pair.num_nodes, nbits, bitmap.data_ptr(),
-                                               _lib.stream()), "ceeg_neg_filter_build")
-            pair.neg_filter = (bitmap, nbits)
-        filt, bits = pair.neg_filter
+    filt, bits = _neg_filter(pair)
     with _lib.timed("neg_sample"):
         _lib.check(L.ceeg_neg_sample_uniform_filtered(pair.rowptr.data_ptr(), pair.col.data_ptr(), int(num_nodes), int(num), int(seed), _lib.ptr(filt),
                                                       bits, out[0].data_ptr(), out[1].data_ptr(), _lib.stream()), "ceeg_neg_sample_uniform_filtered")
@@ -898,16 +931,18 @@ class _FusedDecoder(torch.autograd.Function):
                                                     cp.data_ptr(), cn.data_ptr(), 2, _lib.ptr(grow), None if grow is None else grow[1].data_ptr(), D,
                                                     sums.data_ptr(), p.max_row, ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_decoder_fused_fwd")
             ctx.grow = grow
-        inv = torch.stack([torch.full((), 1.0 / max(p.nnz, 1), dtype=torch.float32, device=z.device), 1.0 / sums[2].clamp(min=1.0)])
-        ctx.save_for_backward(z, coef, inv)
+        out = torch.empty(6, dtype=torch.float32, device=z.device)   # rec, 1/E_pos, 1/valid negatives, then the three sums again
+        _lib.check(L.ceeg_recon_finish(sums.data_ptr(), sums[1:].data_ptr(), sums[2:].data_ptr(), float(max(p.nnz, 1)), out.data_ptr(),
+                                       _lib.stream()), "ceeg_recon_finish")
+        ctx.save_for_backward(z, coef, out)
         ctx.sidx, ctx.shape = sidx, (N, D)
         ctx.graph, ctx.sig = graph, (a, b, ainv, mod)
         ctx.mark_non_differentiable(sums)
-        return sums[0] * inv[0] + sums[1] * inv[1], sums
+        return out[0], sums
 
     @staticmethod
     def backward(ctx, g, _gs):
-        z, coef, inv = ctx.saved_tensors
+        z, coef, out = ctx.saved_tensors
         L = _lib.lib()
         N, D = ctx.shape
         p = ctx.graph.dec
@@ -915,7 +950,7 @@ class _FusedDecoder(torch.autograd.Function):
         a, b, ainv, mod = ctx.sig
         if a == 0 and not ctx.codes:  # positives only: every cn is 0; sigma is the identity for the backward's addressing
             a, b, ainv = 1, 0, 1          # (the code form takes a == 0 itself and walks only the positive lists)
-        gscale = (inv * g).contiguous()
+        gscale = (out[1:3] * g).contiguous()
         dz = torch.empty(N, D, dtype=torch.float32, device=z.device)
         if ctx.codes:
             li, lt = ctx.items
@@ -1062,14 +1097,16 @@ class VGAEVQ(nn.Module):
         ml, z, kl, vq_loss, z_q, ppl, idx = self.encoder.encode_reparam_vq(x, graph, eps, seed, self.training, self.vector_quantization)
         if self.negatives == "uniform" or neg_edge_index is not None:
             # literal path: recon_loss(z_q, pos_edge_index, negative_sampling(...)) - one fresh sample set per step
-            if neg_edge_index is None:
-                neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
             W, code = self.vector_quantization.embedding.weight, idx.view(-1).to(torch.int32)
             codes_on = os.environ.get("CEEG_DEC_CODES", "1") == "1" and os.environ.get("CEEG_PAIR_CODES", "1") == "1"
-            if codes_on and graph.num_edges > 0 and _UniformRecon.supported(W, N, neg_edge_index.shape[1]):
-                rec, sums = _UniformRecon.apply(z_q, graph, neg_edge_index, W, code)   # both pair sets in code form, one dz
+            n_neg = graph.num_edges if neg_edge_index is None else neg_edge_index.shape[1]
+            if codes_on and graph.num_edges > 0 and N > 1 and _UniformRecon.supported(W, N, n_neg):
+                # both pair sets in code form, one dz; with no list given the pairs are drawn inside the forward kernel
+                rec, sums, neg_edge_index = _UniformRecon.apply(z_q, graph, neg_edge_index, W, code, self.negative_seed(step), n_neg)
                 loss = rec + kl / N + vq_loss
                 return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums, neg_edge_index=neg_edge_index)
+            if neg_edge_index is None:
+                neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
             if (os.environ.get("CEEG_DEC_CODES", "1") == "1" and graph.num_edges > 0
                     and _lib.lib().ceeg_decoder_codes_supported(int(W.shape[0]), int(W.shape[1])) == 1):
                 # positives: the CSR-ordered code-form decoder with its negatives switched off (sig_a = 0)

@@ -331,6 +331,25 @@ int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const i
 int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const uint32_t* keys,
                             const float* coef_table, int64_t E, int64_t N, const float* gscale, int accumulate, float* dz,
                             int64_t lddz, void* ws, size_t ws_bytes, void* stream);
+/* negative_sampling fused into the pair-list forward: pair k is DRAWN inside the kernel (the samples of
+ * ceeg_neg_sample_uniform_filtered bit for bit, written to neg_src / neg_dst as that call writes them) and goes straight into the
+ * term lookup and the incidence keys - loss_sum, keys and coef_table equal the two calls run one after the other, exactly; the
+ * 128 MB pair list is written once and never re-read.  rowptr / col: the positives' CSR the sampler rejects against. */
+int ceeg_neg_sample_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int D, const int32_t* code, const int32_t* rowptr,
+                                       const int32_t* col, int64_t N, int64_t num, uint64_t seed, const uint32_t* filter,
+                                       int filter_bits, int32_t* neg_src, int32_t* neg_dst, uint32_t* keys, float* coef_table,
+                                       float* loss_sum, void* ws, size_t ws_bytes, void* stream);
+/* The backward of BOTH pair sets of the literal recon_loss in one gradient kernel: ceeg_decoder_codes_bwd with sig_a = 0 (the
+ * positives' three lists) plus the sampled pairs' incidence keys (ceeg_pair_bce_codes_fwd) sorted by node as a FOURTH list of every
+ * node: dz = gscale[0] * (positives) + gscale[1] * sum_keys C[code n][key & 1023] W[key & 1023], written once - bitwise what
+ * ceeg_decoder_codes_bwd followed by ceeg_pair_bce_codes_bwd(accumulate = 1) leaves, without the second slab fill and the
+ * read-modify-write of the [N, D] gradient. */
+size_t ceeg_decoder_codes_bwd_pairs_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong, int64_t E);
+int ceeg_decoder_codes_bwd_pairs(const float* W, int64_t ldw, int n_e, int D, const int32_t* rowptr, const int32_t* t_rowptr,
+                                 const int32_t* t_perm, int64_t N, int64_t nnz, const int32_t* long_items, int64_t n_long,
+                                 const int32_t* t_long_items, int64_t n_tlong, int64_t max_row_nnz, int64_t max_trow_nnz,
+                                 const void* rec, const int32_t* code, const uint32_t* keys, const float* coef_table, int64_t E,
+                                 const float* gscale, float* dz, int64_t lddz, void* ws, size_t ws_bytes, void* stream);
 int ceeg_decoder_codes_chunk(void);
 int ceeg_decoder_codes_supported(int n_e, int D);
 size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong);
@@ -355,6 +374,11 @@ size_t ceeg_colsum_ws_bytes(int64_t N, int F);
 int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F,
                          float* colsum, void* ws, size_t ws_bytes, void* stream);
 int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, void* ws, size_t ws_bytes, void* stream);
+
+/* recon_loss's last step (upstream PyG GAE.recon_loss: pos_loss.mean() + neg_loss.mean()) in one launch:
+ *   out[0] = pos_sum / pos_count + neg_sum / max(neg_count, 1);  out[1] = 1 / pos_count;  out[2] = 1 / max(neg_count, 1);
+ *   out[3..5] = pos_sum, neg_sum, neg_count.   pos_sum / neg_sum / neg_count: one device float each; out: 6 device floats. */
+int ceeg_recon_finish(const float* pos_sum, const float* neg_sum, const float* neg_count, float pos_count, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N1  GATConv attention (upstream PyG GATConv, instantiated by the reference at scripts/models.py:106), one head per
