@@ -124,6 +124,78 @@ __device__ __forceinline__ void ceeg_neg_draw(const int32_t* __restrict__ rowptr
   }
 }
 
+// U samples (k[0..U)) drawn in LOCKSTEP by one thread: the same candidates, tests and results as U calls of ceeg_neg_draw, but
+// the dependent loads of the U samples (filter word -> row pointers -> binary-search probes) are issued side by side, so a
+// thread keeps U random reads in flight instead of one (the sampler is latency-bound: ~6 % of the candidates hit a set filter
+// bit and take a row search, and with 64 lanes nearly every wave waits for one of them).  live[u] = false skips sample u.
+template <bool FILTER, int U>
+__device__ __forceinline__ void ceeg_neg_draw_multi(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
+                                                    uint64_t seed, const int64_t (&k)[U], const bool (&live)[U],
+                                                    const uint32_t* __restrict__ filter, unsigned filter_bits, int32_t (&s)[U],
+                                                    int32_t (&d)[U]) {
+  bool open[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) { s[u] = -1; d[u] = -1; open[u] = live[u]; }
+  for (uint32_t a = 0; a < 16; ++a) {  // bounded: every lane leaves after at most 16 attempts
+    bool any_open = false;
+#pragma unroll
+    for (int u = 0; u < U; ++u) any_open |= open[u];
+    if (!any_open) break;
+    int32_t cs[U], cd[U];
+    uint32_t fw[U];
+    bool search[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // candidates + filter words, all U loads issued before any is used
+      const uint4 x = ceeg_philox(seed, (uint32_t)k[u], (uint32_t)((uint64_t)k[u] >> 32), CEEG_TAG_NEG, a);
+      cs[u] = (int32_t)(((uint64_t)x.x * (uint64_t)N) >> 32);
+      cd[u] = (int32_t)(((uint64_t)x.y * (uint64_t)N) >> 32);
+      search[u] = open[u] && cs[u] != cd[u];
+      fw[u] = ~0u;
+      if (FILTER && search[u]) {
+        const uint32_t h = neg_filter_hash(cs[u], cd[u], filter_bits);
+        fw[u] = __builtin_nontemporal_load(filter + (h >> 5)) >> (h & 31);  // single-use lines of a 32 MiB bitmap: keep L2 for the codes
+      }
+    }
+    int lo[U], hi[U], end[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (search[u] && (fw[u] & 1u) == 0u) {  // clear bit: not an edge
+        s[u] = cs[u]; d[u] = cd[u];
+        open[u] = false;
+        search[u] = false;
+      }
+      lo[u] = 0; hi[u] = 0; end[u] = 0;
+      if (search[u]) { lo[u] = rowptr[cd[u]]; end[u] = rowptr[cd[u] + 1]; hi[u] = end[u]; }
+    }
+    for (;;) {  // the U binary searches of csr_has, one probe of each per round
+      bool more = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) more |= search[u] && lo[u] < hi[u];
+      if (!more) break;
+      int c[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        c[u] = 0;
+        if (search[u] && lo[u] < hi[u]) c[u] = col[(lo[u] + hi[u]) >> 1];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (search[u] && lo[u] < hi[u]) {
+          const int mid = (lo[u] + hi[u]) >> 1;
+          if (c[u] < cs[u]) lo[u] = mid + 1; else hi[u] = mid;
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (search[u]) {
+        const bool is_edge = lo[u] < end[u] && col[lo[u]] == cs[u];
+        if (!is_edge) { s[u] = cs[u]; d[u] = cd[u]; open[u] = false; }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- internal cross-file launchers
 // Extra addressing for the SpMM used by the fused decoder backward: affine (bijective) maps on the
 // gathered column index and on the output row, and a device-side scale applied to the row sum.

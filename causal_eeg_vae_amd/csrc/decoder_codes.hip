@@ -835,7 +835,14 @@ __global__ __launch_bounds__(256) void dc_pair_tables_kernel(const float* __rest
   C[i] = negative ? cn : cp;
 }
 
-__global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ T, int K, const int32_t* __restrict__ code,
+// codes as clamped 16-bit values: the array the pair kernels read at random shrinks to 2 bytes per node (2 MB at N = 1 M) and
+// stays in L2 next to the 1 MB term table while the pair / key streams and the sampler's bitmap lines flow past
+__global__ __launch_bounds__(256) void dc_code16_kernel(const int32_t* __restrict__ code, int64_t N, int K, unsigned short* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = (unsigned short)dc_clamp_code(code[i], K);
+}
+
+__global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ T, int K, const unsigned short* __restrict__ code,
                                                           const int32_t* __restrict__ ei, const int32_t* __restrict__ ej, int64_t E, int64_t N,
                                                           uint2* __restrict__ keys, float* __restrict__ part) {
   __shared__ float red[2][4];
@@ -844,8 +851,8 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
     const int ni = __builtin_nontemporal_load(ei + e), nj = __builtin_nontemporal_load(ej + e);  // streams: leave L2 to code[] and T
     unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
     if (ni >= 0 && nj >= 0 && ni < N && nj < N) {
-      ki = (unsigned)dc_clamp_code(code[ni], K);
-      kj = (unsigned)dc_clamp_code(code[nj], K);
+      ki = code[ni];
+      kj = code[nj];
       acc += T[(size_t)ki * K + kj];
       cnt += 1.0f;
       key_i = (unsigned)ni;
@@ -873,31 +880,51 @@ __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restric
 // for bit), writes it out (the caller's neg_edge_index) and goes on as dc_pair_fwd_kernel does - same grid, same per-thread
 // strides, same partial layout, so loss and keys equal the two-launch form exactly.  The 128 MB pair list is never re-read.
 template <bool FILTER>
-__global__ __launch_bounds__(256) void dc_sample_pair_fwd_kernel(const float* __restrict__ T, int K, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256) void dc_sample_pair_fwd_kernel(const float* __restrict__ T, int K, const unsigned short* __restrict__ code,
                                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                  int64_t N, int64_t E, uint64_t seed, const uint32_t* __restrict__ filter,
                                                                  unsigned filter_bits, int32_t* __restrict__ neg_src,
                                                                  int32_t* __restrict__ neg_dst, uint2* __restrict__ keys,
                                                                  float* __restrict__ part) {
+  constexpr int U = 4;  // samples a thread draws in lockstep (its next U grid-stride iterations): U random reads in flight
   __shared__ float red[2][4];
   float acc = 0.f, cnt = 0.f;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
-    int32_t ni, nj;
-    ceeg_neg_draw<FILTER>(rowptr, col, N, seed, e, filter, filter_bits, ni, nj);
-    __builtin_nontemporal_store(ni, neg_src + e);
-    __builtin_nontemporal_store(nj, neg_dst + e);
-    unsigned key_i = (unsigned)N, key_j = (unsigned)N, ki = 0, kj = 0;
-    if (ni >= 0 && nj >= 0) {
-      ki = (unsigned)dc_clamp_code(code[ni], K);
-      kj = (unsigned)dc_clamp_code(code[nj], K);
-      acc += T[(size_t)ki * K + kj];
-      cnt += 1.0f;
-      key_i = (unsigned)ni;
-      key_j = (unsigned)nj;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t e0 = (int64_t)blockIdx.x * 256 + threadIdx.x; e0 < E; e0 += U * stride) {
+    int64_t ek[U];
+    bool live[U];
+    int32_t ni[U], nj[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { ek[u] = e0 + u * stride; live[u] = ek[u] < E; }
+    ceeg_neg_draw_multi<FILTER, U>(rowptr, col, N, seed, ek, live, filter, filter_bits, ni, nj);
+    unsigned ki[U], kj[U];
+    float t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      ki[u] = 0; kj[u] = 0;
+      if (live[u] && ni[u] >= 0) { ki[u] = (unsigned)code[ni[u]]; kj[u] = (unsigned)code[nj[u]]; }
     }
-    if (keys) {
-      __builtin_nontemporal_store((key_j << DC_PAIR_NODE_SHIFT) | ki, &keys[e].x);
-      __builtin_nontemporal_store((key_i << DC_PAIR_NODE_SHIFT) | kj, &keys[e].y);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      t[u] = 0.f;
+      if (live[u] && ni[u] >= 0) t[u] = T[(size_t)ki[u] * K + kj[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {  // sums in ascending-e order, as the one-sample-at-a-time loop adds them
+      if (!live[u]) continue;
+      unsigned key_i = (unsigned)N, key_j = (unsigned)N;
+      if (ni[u] >= 0) {
+        acc += t[u];
+        cnt += 1.0f;
+        key_i = (unsigned)ni[u];
+        key_j = (unsigned)nj[u];
+      }
+      __builtin_nontemporal_store(ni[u], neg_src + ek[u]);
+      __builtin_nontemporal_store(nj[u], neg_dst + ek[u]);
+      if (keys) {
+        __builtin_nontemporal_store((key_j << DC_PAIR_NODE_SHIFT) | ki[u], &keys[ek[u]].x);
+        __builtin_nontemporal_store((key_i << DC_PAIR_NODE_SHIFT) | kj[u], &keys[ek[u]].y);
+      }
     }
   }
   acc = ceeg_wave_sum(acc);
@@ -1047,8 +1074,8 @@ size_t dc_pair_bwd_layout(int64_t E, int64_t N, void* ws, size_t ws_bytes, DcPai
   }
   return need;
 }
-size_t dc_pair_fwd_bytes(int n_e) {  // G, T, block partials (+ 3 floats for the finalize)
-  return 2 * ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4);
+size_t dc_pair_fwd_bytes(int n_e, int64_t N) {  // G, T, block partials (+ 3 floats for the finalize), 16-bit codes
+  return 2 * ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4) + ceeg_ws_part((size_t)N, 2);
 }
 
 }  // namespace
@@ -1057,7 +1084,7 @@ extern "C" int ceeg_pair_bce_codes_supported(int n_e, int D, int64_t N, int64_t 
 
 extern "C" size_t ceeg_pair_bce_codes_ws_bytes(int64_t E, int64_t N, int n_e) {
   if (E < 0 || N <= 0 || N > DC_PAIR_MAX_N || n_e <= 0 || E >= ((int64_t)1 << 30)) return 0;
-  const size_t fwd = dc_pair_fwd_bytes(n_e);
+  const size_t fwd = dc_pair_fwd_bytes(n_e, N);
   const size_t bwd = dc_pair_bwd_layout(E, N, nullptr, 0, nullptr);
   return fwd > bwd ? fwd : bwd;
 }
@@ -1068,19 +1095,22 @@ extern "C" int ceeg_pair_bce_codes_fwd(const float* W, int64_t ldw, int n_e, int
   if (!W || !code || !loss_sum || !coef_table || E < 0 || N <= 0 || (E > 0 && (!i || !j))) return CEEG_EINVAL;
   if (!dc_pair_supported(n_e, D, N, E)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && !ceeg_aligned(keys, 8)) || !ceeg_aligned(coef_table, 4)) return CEEG_EINVAL;
-  if (ws_bytes < dc_pair_fwd_bytes(n_e) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (ws_bytes < dc_pair_fwd_bytes(n_e, N) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t kk = ceeg_ws_part((size_t)n_e * n_e, 4);
   float* G = static_cast<float*>(ws);
   float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + kk);
   float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * kk);
+  unsigned short* code16 = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + 2 * kk + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4));
+  hipLaunchKernelGGL(dc_code16_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, code, N, n_e, code16);
+  CEEG_CHECK_LAUNCH();
   hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
   CEEG_CHECK_LAUNCH();
   hipLaunchKernelGGL(dc_pair_tables_kernel, dim3((unsigned)((n_e * n_e + 255) / 256)), dim3(256), 0, st, G, n_e, negative & 1, T, coef_table);
   CEEG_CHECK_LAUNCH();
   int64_t nb = (E + 255) / 256;
   nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
-  hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, i, j, E, N, reinterpret_cast<uint2*>(keys), part);
+  hipLaunchKernelGGL(dc_pair_fwd_kernel, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code16, i, j, E, N, reinterpret_cast<uint2*>(keys), part);
   CEEG_CHECK_LAUNCH();
   float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
   hipLaunchKernelGGL(dc_finalize_kernel, dim3(1), dim3(1024), 0, st, part, nb, tmp);
@@ -1134,12 +1164,15 @@ extern "C" int ceeg_neg_sample_pair_bce_codes_fwd(const float* W, int64_t ldw, i
   if (filter && (filter_bits < 13 || filter_bits > 32)) return CEEG_EINVAL;
   if (!dc_pair_supported(n_e, D, N, num)) return CEEG_EUNSUPPORTED;
   if (ldw < D || (ldw % 4) != 0 || !ceeg_aligned(W, 16) || (keys && !ceeg_aligned(keys, 8)) || !ceeg_aligned(coef_table, 4)) return CEEG_EINVAL;
-  if (ws_bytes < dc_pair_fwd_bytes(n_e) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (ws_bytes < dc_pair_fwd_bytes(n_e, N) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t kk = ceeg_ws_part((size_t)n_e * n_e, 4);
   float* G = static_cast<float*>(ws);
   float* T = reinterpret_cast<float*>(static_cast<char*>(ws) + kk);
   float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + 2 * kk);
+  unsigned short* code16 = reinterpret_cast<unsigned short*>(static_cast<char*>(ws) + 2 * kk + ceeg_ws_part((size_t)(DC_EDGE_BLOCKS + 1) * 3, 4));
+  hipLaunchKernelGGL(dc_code16_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, code, N, n_e, code16);
+  CEEG_CHECK_LAUNCH();
   hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
   CEEG_CHECK_LAUNCH();
   hipLaunchKernelGGL(dc_pair_tables_kernel, dim3((unsigned)((n_e * n_e + 255) / 256)), dim3(256), 0, st, G, n_e, 1, T, coef_table);
@@ -1147,10 +1180,10 @@ extern "C" int ceeg_neg_sample_pair_bce_codes_fwd(const float* W, int64_t ldw, i
   int64_t nb = (num + 255) / 256;
   nb = nb < 1 ? 1 : (nb > DC_EDGE_BLOCKS ? DC_EDGE_BLOCKS : nb);
   if (filter)
-    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, rowptr, col, N, num, seed, filter,
+    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code16, rowptr, col, N, num, seed, filter,
                        (unsigned)filter_bits, neg_src, neg_dst, reinterpret_cast<uint2*>(keys), part);
   else
-    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code, rowptr, col, N, num, seed, filter,
+    hipLaunchKernelGGL(dc_sample_pair_fwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, st, T, n_e, code16, rowptr, col, N, num, seed, filter,
                        0u, neg_src, neg_dst, reinterpret_cast<uint2*>(keys), part);
   CEEG_CHECK_LAUNCH();
   float* tmp = part + (size_t)DC_EDGE_BLOCKS * 3;
