@@ -1302,6 +1302,11 @@ int vq_static_scratch_ptr(void** out) {
 
 extern "C" size_t ceeg_vq_forward_static_max_bytes(void) { return VQ_STATIC_SCRATCH_BYTES; }
 
+extern "C" int ceeg_vq_forward_static_prepare(void) {  // the per-device set-up of ceeg_vq_forward_static, callable on its own
+  void* scratch = nullptr;
+  return vq_static_scratch_ptr(&scratch);
+}
+
 extern "C" int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
                                       void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist, void* stream) {
   const int rc = vq_forward_check(z, W, B, n_e, D, dtype, z_q, idx, loss, perplexity);

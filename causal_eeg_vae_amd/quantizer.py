@@ -87,7 +87,12 @@ class VectorQuantizer(nn.Module):
         self.embedding = nn.Embedding(self.n_e, self.e_dim)
         self.embedding.weight.data.uniform_(-1.0 / self.n_e, 1.0 / self.n_e)
 
+    MAX_N_E, MAX_E_DIM = 4096, 256   # what libceeg's kernels are tested for (include/ceeg.h, ceeg_vq_forward)
+
     def forward(self, z):
+        if self.n_e > self.MAX_N_E or self.e_dim > self.MAX_E_DIM:
+            raise _lib.CeegError(f"VectorQuantizer: n_e = {self.n_e}, e_dim = {self.e_dim} is outside what the HIP kernels take "
+                                 f"(n_e <= {self.MAX_N_E}, e_dim <= {self.MAX_E_DIM}); there is no fallback path")
         loss, z_q, perplexity, min_encoding_indices = _VQFunction.apply(z, self.embedding.weight, self.beta)
         min_encodings = None
         if self.return_one_hot:

@@ -1,6 +1,8 @@
 """Config-1 plumbing (BASELINE.json configs[0]): the on-disk CSV pair of the reference -> event graph -> GCN-VGAE + VQ
 training on the GPU.  The host loop of /root/reference/scripts/run.py:54-135 restated for this model: epochs of
-optimizer steps (Adam 1e-3, scripts/run.py:56), `ReduceLROnPlateau` on the epoch loss (:57,131), best-loss bookkeeping.
+optimizer steps (Adam 1e-3, scripts/run.py:56) and `ReduceLROnPlateau` (:57) stepped once per epoch.  Two differences from the
+reference's loop, both because there is no validation split here: the scheduler sees the TRAINING epoch loss (the reference
+steps it on the validation loss, :136), and no best-loss checkpointing / early stopping is kept (:139-149).
 
     python -m causal_eeg_vae_amd.run_csv NODES.csv EDGES.csv [--epochs 5 --steps-per-epoch 20 --latent 16 --codes 64]
 

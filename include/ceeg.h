@@ -86,7 +86,11 @@ int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, in
  * launch; config 3 (4 Mi x 512 x 256, both dtypes: 2.63 MiB) fits.  Calls no hipMalloc/hipFree or allocating routine.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE - serialise
  * them.  Nothing in the array has to be zero between calls (every word a kernel reads is written earlier in the same
- * call).  The one exception to "no global mutable state" above: the per-device address of the array, looked up once. */
+ * call).  The one exception to "no global mutable state" above: the per-device address of the array, looked up once.
+ * Set-up: the array's device address is looked up (hipGetSymbolAddress, under a mutex) on the FIRST call on each device; that
+ * lookup may load the code object and is not capture-safe.  Call ceeg_vq_forward_static_prepare() once per device, with that device
+ * current, outside any stream capture (or make the first ceeg_vq_forward_static call there); calls after it only launch kernels. */
+int ceeg_vq_forward_static_prepare(void);
 size_t ceeg_vq_forward_static_max_bytes(void);
 int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,
                            void* z_q, int64_t* idx, float* loss, float* perplexity, uint32_t* hist, void* stream);

@@ -21,6 +21,9 @@ def _call(static, z, W, beta):
     sc = torch.empty(2, dtype=torch.float32, device=z.device)
     hist = torch.empty(n_e, dtype=torch.int32, device=z.device)
     if static:
+        _lib.check(L.ceeg_vq_forward_static_prepare(), "prepare")   # per-device set-up (the symbol lookup), outside the measured call
+        torch.cuda.synchronize()
+        free0, alloc0 = torch.cuda.mem_get_info()[0], torch.cuda.memory_allocated()
         rc = L.ceeg_vq_forward_static(z.data_ptr(), W.data_ptr(), B, n_e, D, dt, beta, z_q.data_ptr(), idx.data_ptr(),
                                       sc[0:].data_ptr(), sc[1:].data_ptr(), hist.data_ptr(), _lib.stream())
     else:
@@ -29,6 +32,8 @@ def _call(static, z, W, beta):
                                sc[0:].data_ptr(), sc[1:].data_ptr(), hist.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream())
     _lib.check(rc, "vq forward")
     torch.cuda.synchronize()
+    if static:   # the entry point allocated nothing: neither through torch nor behind its back (driver-level free memory)
+        assert torch.cuda.memory_allocated() == alloc0 and torch.cuda.mem_get_info()[0] == free0
     return z_q, idx, sc, hist
 
 
