@@ -75,6 +75,7 @@ class CollatedBatch:
             checks = {("intra", n): ok}
         g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks)
         g.batch = self.batch
+        g.reuse = False          # a minibatch graph lives for one step: no per-graph packing of the value stream
         return g
 
     def separate(self, idx):

@@ -216,6 +216,7 @@ struct CeegSpmmEx {
   int64_t n_long_items = 0;
   int nt = 0;                     // bit 0: non-temporal stores of out; bit 1: non-temporal loads of the col / val streams
   const int32_t* xidx = nullptr;  // row indirection for X (after the column map): gather X[xidx[c]] - X is then a small table
+  const int2* colval = nullptr;   // (col, val bits) interleaved: one 8-byte stream instead of two 4-byte ones (col / val arguments then unused)
   const float* mask = nullptr;    // [N, ld_mask]: the finished row is multiplied by (mask[r, f] > 0) - a ReLU's backward mask, applied
   int64_t ld_mask = 0;            // to the gradient the pass produces (the mask row is fetched before the gathers, off the critical path)
 };

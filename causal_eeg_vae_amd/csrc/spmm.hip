@@ -72,6 +72,14 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
                                            int& my_c, float& my_v) {
   my_c = 0;
   my_v = 0.f;
+  if (ex.colval) {
+    if (base + lane < p_hi) {
+      const int2 cv = ex.colval[base + lane];
+      my_c = cv.x;
+      my_v = __int_as_float(cv.y);
+    }
+    return;
+  }
   if (base + lane < p_hi) {
     my_c = (ex.nt & 2) ? __builtin_nontemporal_load(col + base + lane) : col[base + lane];
     if (ex.col_a != 1 || ex.col_b != 0) my_c = (int)ceeg_block_affine((int64_t)my_c, ex.col_a, ex.col_b, ex.mod);
@@ -508,7 +516,8 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
                      const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
                      int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
                      const CeegSpmmEx& ex) {
-  if (N <= 0 || nnz < 0 || !rowptr || !X || !out || (nnz > 0 && (!col || !val))) return CEEG_EINVAL;
+  if (N <= 0 || nnz < 0 || !rowptr || !X || !out || (nnz > 0 && !ex.colval && (!col || !val))) return CEEG_EINVAL;
+  if (ex.colval && (vperm || ex.xidx || ex.val_stride != 1 || ex.col_a != 1 || ex.col_b != 0 || !ceeg_aligned(ex.colval, 8))) return CEEG_EINVAL;
   if (F < 4 || F > 1024 || (F % 4) != 0 || (ldx % 4) != 0 || (ldo % 4) != 0 || ldx < F || ldo < F) return CEEG_EUNSUPPORTED;
   if (!ceeg_aligned(X, 16) || !ceeg_aligned(out, 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
   if (nnz >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
@@ -599,5 +608,27 @@ extern "C" int ceeg_spmm_csr_masked(const int32_t* rowptr, const int32_t* col, c
   ex.mask = mask;
   ex.ld_mask = ld_mask;
   return ceeg_spmm_launch(rowptr, col, val, vperm, X, ldx, N, nnz, F, nullptr, 0, 0, out, ldo, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream), ex);
+}
+
+// ceeg_spmm_csr_items / ceeg_spmm_csr_masked with the (column, value) pairs of the CSR interleaved into one 8-byte stream
+extern "C" int ceeg_spmm_csr_cv(const int32_t* rowptr, const void* colval, const float* X, int64_t ldx, int64_t N, int64_t nnz, int F,
+                                const float* bias, int relu, const float* mask, int64_t ld_mask, float* out, int64_t ldo,
+                                int64_t max_row_nnz, const int32_t* long_items, int64_t n_long, void* ws, size_t ws_bytes, void* stream) {
+  if (!colval && nnz > 0) return CEEG_EINVAL;
+  if (mask && (ld_mask < F || (ld_mask % 4) != 0 || !ceeg_aligned(mask, 16))) return CEEG_EINVAL;
+  if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
+  if (max_row_nnz < 0 || (max_row_nnz > SPMM_CHUNK && n_long == 0)) return CEEG_EINVAL;
+  static const int32_t no_items[4] = {0, 0, 0, 0};
+  static const int2 no_cv = {0, 0};
+  CeegSpmmEx ex;
+  ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
+  ex.long_items = n_long > 0 ? long_items : no_items;
+  ex.n_long_items = n_long;
+  ex.mask = mask;
+  ex.ld_mask = ld_mask;
+  ex.colval = colval ? static_cast<const int2*>(colval) : &no_cv;
+  return ceeg_spmm_launch(rowptr, nullptr, nullptr, nullptr, X, ldx, N, nnz, F, bias, relu, 0, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }

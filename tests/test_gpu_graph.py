@@ -340,3 +340,32 @@ def test_device_collation_follow_batch_and_separate_round_trip():
     assert n2 == offs and torch.equal(e2, c.edge_index) and torch.equal(b2, c.batch)
     L = __import__("causal_eeg_vae_amd")._lib.lib()
     assert L.ceeg_collate_edges(None, 0, c.ptr.data_ptr(), c.ptr.data_ptr(), 0, 5, 1, None, 0, None, None) < 0   # G = 0: refused
+
+
+@pytest.mark.parametrize("F", [128, 256, 40])
+def test_interleaved_value_stream_and_masked_aggregation_bitwise(F, monkeypatch):
+    """EventGraph.aggregate (ceeg_spmm_csr_cv: (column, value) pairs in one 8-byte stream) equals ceeg_spmm_csr_items bit for bit -
+    with bias + ReLU, hub rows included - and ceeg_spmm_csr_masked / the masked cv form equal the plain transposed pass followed by
+    the ReLU mask (g * (y > 0))."""
+    from causal_eeg_vae_amd import EventGraph, _lib
+    from causal_eeg_vae_amd.models import _spmm, _spmm_cv
+    N, E = 5000, 80000
+    src, dst = _rand_graph(N, E, F + 1, hubs=3000)
+    g = EventGraph(torch.from_numpy(np.stack([src, dst])).cuda(), N)
+    p = g.gcn
+    x = torch.randn(N, F, device="cuda")
+    bias = torch.randn(F, device="cuda")
+    want = _spmm(p.rowptr, p.col, g.gcn_val, None, x, N, bias=bias, relu=True, max_row=p.max_row, items=p.long_items(False))
+    got = g.aggregate(x, bias=bias, relu=True)
+    assert g._gcn_cv is not None and torch.equal(got, want)
+    monkeypatch.setenv("CEEG_SPMM_CV", "0")
+    assert torch.equal(g.aggregate(x, bias=bias, relu=True), want)
+    y = torch.randn(N, F, device="cuda")
+    plain = _spmm(p.t_rowptr, p.t_col, g.gcn_tval, None, x, N, max_row=p.max_trow, items=p.long_items(True))
+    masked = _spmm(p.t_rowptr, p.t_col, g.gcn_tval, None, x, N, max_row=p.max_trow, items=p.long_items(True), mask=y)
+    assert torch.equal(masked, plain * (y > 0))
+    tcv = torch.stack([p.t_col, g.gcn_tval.view(torch.int32)], dim=1).contiguous()
+    assert torch.equal(_spmm_cv(p.t_rowptr, tcv, x, N, p.nnz, mask=y, max_row=p.max_trow, items=p.long_items(True)), masked)
+    L = _lib.lib()
+    ptr = x.data_ptr()
+    assert L.ceeg_spmm_csr_cv(p.rowptr.data_ptr(), None, ptr, F, N, p.nnz, F, None, 0, None, 0, ptr, F, 0, None, 0, ptr, 1 << 20, _lib.stream()) == -1
