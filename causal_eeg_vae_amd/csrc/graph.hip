@@ -14,7 +14,9 @@ namespace {
 
 constexpr uint64_t KEY_INVALID = ~0ull;
 
-__global__ void csr_edge_keys_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int64_t N,
+// Keys are (dst << nb | src) with nb = key_bits(N): the sort then runs over 2 nb bits (40 at N = 1 M: five 8-bit passes) instead of
+// the 32 + nb of a (dst << 32 | src) layout (seven passes).  The all-ones key of a dropped edge has a dst field >= N and sorts last.
+__global__ void csr_edge_keys_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int64_t N, unsigned nb,
                                      int self_loops, uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
                                      int32_t* __restrict__ loop_eid) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -25,23 +27,23 @@ __global__ void csr_edge_keys_kernel(const int64_t* __restrict__ src, const int6
     if (self_loops && s == d) {
       atomicMax(&loop_eid[s], (int32_t)e);  // integer max: order-independent -> deterministic
     } else {
-      key = ((uint64_t)d << 32) | (uint64_t)s;
+      key = ((uint64_t)d << nb) | (uint64_t)s;
     }
   }
   keys[e] = key;
   vals[e] = (int32_t)e;
 }
 
-__global__ void csr_loop_keys_kernel(int64_t E, int64_t N, uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
+__global__ void csr_loop_keys_kernel(int64_t E, int64_t N, unsigned nb, uint64_t* __restrict__ keys, int32_t* __restrict__ vals,
                                      const int32_t* __restrict__ loop_eid) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  keys[E + i] = ((uint64_t)i << 32) | (uint64_t)i;
+  keys[E + i] = ((uint64_t)i << nb) | (uint64_t)i;
   vals[E + i] = loop_eid[i];  // last existing self-loop's edge id (its weight survives) or -1
 }
 
 // sorted keys -> rowptr / col / perm.  Thread p closes every row between key[p-1] and key[p].
-__global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t M, int64_t N,
+__global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t M, int64_t N, unsigned nb,
                                   int32_t* __restrict__ rowptr, int32_t* __restrict__ col, int32_t* __restrict__ perm,
                                   int64_t* __restrict__ nnz_out) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -49,15 +51,15 @@ __global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32
   int64_t d_cur = N, d_prev = -1;
   if (p < M) {
     const uint64_t k = keys[p];
-    const int64_t d = (int64_t)(k >> 32);
+    const int64_t d = (int64_t)(k >> nb);
     d_cur = d < N ? d : N;
     if (d < N) {
-      col[p] = (int32_t)(k & 0xffffffffu);
+      col[p] = (int32_t)(k & ((1ull << nb) - 1));
       perm[p] = vals[p];
     }
   }
   if (p > 0) {
-    const int64_t d = (int64_t)(keys[p - 1] >> 32);
+    const int64_t d = (int64_t)(keys[p - 1] >> nb);
     d_prev = d < N ? d : N;
   }
   for (int64_t r = d_prev + 1; r <= d_cur; ++r) {
@@ -66,17 +68,41 @@ __global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32
   }
 }
 
-// entry p of row r -> key (col[p] << 32 | r), value p
-__global__ void csr_transpose_keys_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
-                                          uint64_t* __restrict__ keys, int32_t* __restrict__ vals) {
+// Transpose by ONE stable sort on the column alone: the input CSR is ordered by (row, col), so a stable sort of its entries by
+// col leaves them ordered by (col, row, position) - the transposed CSR's order - with 32-bit keys over nb bits (three 8-bit passes
+// at N = 1 M) instead of 64-bit (col, row) keys over 2 nb.  rowid[p] = row of entry p; positions no row covers keep key 0xffffffff.
+__global__ void csr_transpose_keys32_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
+                                            uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ rowid) {
   const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per row
   if (r >= N) return;
   const int lane = threadIdx.x & 63;
   const int lo = rowptr[r], hi = rowptr[r + 1];
   for (int p = lo + lane; p < hi; p += 64) {
-    keys[p] = ((uint64_t)(uint32_t)col[p] << 32) | (uint64_t)r;
+    keys[p] = (uint32_t)col[p];
     vals[p] = p;
+    rowid[p] = (int32_t)r;
   }
+}
+__global__ void csr_transpose_finish32_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals,
+                                              const int32_t* __restrict__ rowid, int64_t M, int64_t N, int32_t* __restrict__ t_rowptr,
+                                              int32_t* __restrict__ t_col, int32_t* __restrict__ t_perm) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  int64_t cur = N, prev = -1;
+  if (p < M) {
+    const int64_t c = (int64_t)keys[p];
+    cur = c < N ? c : N;
+    if (c < N) {
+      const int32_t v = vals[p];
+      t_perm[p] = v;
+      t_col[p] = rowid[v];
+    }
+  }
+  if (p > 0) {
+    const int64_t c = (int64_t)keys[p - 1];
+    prev = c < N ? c : N;
+  }
+  for (int64_t r = prev + 1; r <= cur; ++r) t_rowptr[r] = (int32_t)p;
 }
 
 __global__ void gcn_deg_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ perm, const float* __restrict__ ew,
@@ -179,7 +205,7 @@ size_t sort_layout(int64_t M, int64_t N, unsigned end_bit, void* ws, size_t ws_b
 extern "C" size_t ceeg_csr_build_ws_bytes(int64_t E, int64_t N, int self_loops) {
   if (E < 0 || N <= 0) return 0;
   const int64_t M = E + (self_loops ? N : 0);
-  return sort_layout(M, N, 32 + key_bits(N), nullptr, 0, nullptr);
+  return sort_layout(M, N, 2 * key_bits(N), nullptr, 0, nullptr);
 }
 
 extern "C" int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int self_loops,
@@ -190,7 +216,7 @@ extern "C" int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E,
   if (M > 0 && (!col || !perm)) return CEEG_EINVAL;
   if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned end_bit = 32 + key_bits(N);
+  const unsigned nb = key_bits(N), end_bit = 2 * nb;
   SortWs w;
   const size_t need = sort_layout(M, N, end_bit, nullptr, 0, nullptr);
   if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
@@ -199,12 +225,12 @@ extern "C" int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E,
     if (hipMemsetAsync(w.loop_eid, 0xff, (size_t)N * 4, st) != hipSuccess) return CEEG_ELAUNCH;
   }
   if (E > 0) {
-    hipLaunchKernelGGL(csr_edge_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, E, N, self_loops,
+    hipLaunchKernelGGL(csr_edge_keys_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, E, N, nb, self_loops,
                        w.keys_in, w.vals_in, w.loop_eid);
     CEEG_CHECK_LAUNCH();
   }
   if (self_loops) {
-    hipLaunchKernelGGL(csr_loop_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, E, N, w.keys_in, w.vals_in, w.loop_eid);
+    hipLaunchKernelGGL(csr_loop_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, E, N, nb, w.keys_in, w.vals_in, w.loop_eid);
     CEEG_CHECK_LAUNCH();
   }
   size_t tb = w.temp_bytes;
@@ -212,15 +238,48 @@ extern "C" int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E,
     if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)M, 0u, end_bit, st, false) != hipSuccess)
       return CEEG_ELAUNCH;
   }
-  hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, M, N, rowptr, col,
+  hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, M, N, nb, rowptr, col,
                      perm, nnz_out);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
 
+namespace {
+struct Sort32Ws {
+  uint32_t *keys_in, *keys_out;
+  int32_t *vals_in, *vals_out, *rowid;
+  void* temp;
+  size_t temp_bytes;
+};
+size_t sort32_temp_bytes(size_t M, unsigned end_bit) {
+  size_t bytes = 0;
+  uint32_t* k = nullptr;
+  int32_t* v = nullptr;
+  if (rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, M, 0u, end_bit, (hipStream_t)0, false) != hipSuccess) return 0;
+  return bytes;
+}
+size_t sort32_layout(int64_t M, unsigned end_bit, void* ws, size_t ws_bytes, Sort32Ws* out) {
+  const size_t tb = sort32_temp_bytes((size_t)M, end_bit);
+  if (tb == 0 && M > 0) return 0;
+  const size_t need = 5 * ceeg_ws_part(M, 4) + ceeg_align_up(tb, 256);
+  if (out) {
+    CeegWs a(ws, ws_bytes);
+    out->keys_in = a.take<uint32_t>(M);
+    out->keys_out = a.take<uint32_t>(M);
+    out->vals_in = a.take<int32_t>(M);
+    out->vals_out = a.take<int32_t>(M);
+    out->rowid = a.take<int32_t>(M);
+    out->temp = a.take<char>(tb);
+    out->temp_bytes = tb;
+    if (!a.ok) return 0;
+  }
+  return need;
+}
+}  // namespace
+
 extern "C" size_t ceeg_csr_transpose_ws_bytes(int64_t nnz, int64_t N) {
   if (nnz < 0 || N <= 0) return 0;
-  return sort_layout(nnz, N, 32 + key_bits(N), nullptr, 0, nullptr);
+  return sort32_layout(nnz, key_bits(N), nullptr, 0, nullptr);
 }
 
 extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, int64_t N,
@@ -229,23 +288,23 @@ extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int
   if (nnz < 0 || N <= 0 || !rowptr || !t_rowptr || (nnz > 0 && (!col || !t_col || !t_perm))) return CEEG_EINVAL;
   if (N >= ((int64_t)1 << 31) || nnz >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const unsigned end_bit = 32 + key_bits(N);
-  SortWs w;
-  const size_t need = sort_layout(nnz, N, end_bit, nullptr, 0, nullptr);
-  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
-  if (sort_layout(nnz, N, end_bit, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  const unsigned nb = key_bits(N);  // the padding key 0xffffffff has all nb low bits set: a column >= N, sorted last
+  Sort32Ws w;
+  const size_t need = sort32_layout(nnz, nb, nullptr, 0, nullptr);
+  if ((need == 0 && nnz > 0) || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (sort32_layout(nnz, nb, ws, ws_bytes, &w) == 0 && nnz > 0) return CEEG_EWORKSPACE;
   // `nnz` may be a CAPACITY (>= rowptr[N], the true count, which then never has to cross to the host): positions the rows do
   // not cover keep the all-ones key, sort behind every entry and are ignored by the finish kernel
-  if (nnz > 0 && hipMemsetAsync(w.keys_in, 0xff, (size_t)nnz * 8, st) != hipSuccess) return CEEG_ELAUNCH;
-  hipLaunchKernelGGL(csr_transpose_keys_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in);
+  if (nnz > 0 && hipMemsetAsync(w.keys_in, 0xff, (size_t)nnz * 4, st) != hipSuccess) return CEEG_ELAUNCH;
+  hipLaunchKernelGGL(csr_transpose_keys32_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in, w.rowid);
   CEEG_CHECK_LAUNCH();
   size_t tb = w.temp_bytes;
   if (nnz > 0) {
-    if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)nnz, 0u, end_bit, st, false) != hipSuccess)
+    if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)nnz, 0u, nb, st, false) != hipSuccess)
       return CEEG_ELAUNCH;
   }
-  hipLaunchKernelGGL(csr_finish_kernel, dim3((unsigned)((nnz + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, nnz, N, t_rowptr,
-                     t_col, t_perm, (int64_t*)nullptr);
+  hipLaunchKernelGGL(csr_transpose_finish32_kernel, dim3((unsigned)((nnz + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, w.rowid,
+                     nnz, N, t_rowptr, t_col, t_perm);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
