@@ -498,8 +498,9 @@ def main():
             tpath = os.path.join(here, "profiles", name)
             if os.path.exists(tpath):
                 t = json.load(open(tpath))
-                if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F) and t.get("negatives", args.negatives) == args.negatives:
-                    traffic = t["traffic_bytes"]
+                if (t.get("nodes"), t.get("edges"), t.get("F")) == (N, E, F):
+                    t = t.get("by_negatives", {}).get(args.negatives, t)
+                    traffic = t.get("traffic_bytes")
                     dec_traffic = t.get("decoder_traffic_bytes")
                 break
         # the decoder of the step that ran (HBM-bound; north star: "HBM GB/s ... for SpMM and the decoder"):

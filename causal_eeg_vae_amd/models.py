@@ -789,6 +789,7 @@ class _UniformRecon(torch.autograd.Function):
         ctx.graph, ctx.items, ctx.shape, ctx.E, ctx.merged = graph, (li, lt), (N, D), E, merged
         sums = out[3:6]
         ctx.mark_non_differentiable(sums, neg_edge_index)
+        ctx.set_materialize_grads(False)   # no zero "gradient" tensors for the integer / statistics outputs (a 128 MB fill per step)
         return out[0], sums, neg_edge_index
 
     @staticmethod
