@@ -572,8 +572,39 @@ def main():
                 line["other_negatives"] = {"negatives": other, "ms_per_step": ms_u, "edges_per_s": E / (ms_u * 1e-3), "steps": args.steps,
                                            "loss": float(lu.item())}
 
+            def leg_bf16():
+                # (2b) the opt-in reduced-precision step beside the fp32 headline (north star: rtol 1e-2 for bf16): bf16 storage of the
+                # encoder's activations (every gathered row half the bytes), bf16 MFMA products, fp32 sums; same sampler as the headline
+                model_b = VGAEVQ(args.in_dim, args.latent, args.codes, 0.25, seed=rank, negatives=args.negatives, compute_dtype=torch.bfloat16).to(dev)
+                model_b.load_state_dict(model.state_dict())
+                tr_b = Trainer(model_b, lr=1e-3, world_size=1)
+                x16 = x.to(torch.bfloat16)
+                for _ in range(args.warmup):
+                    tr_b.step(x16, graph)
+                torch.cuda.synchronize()
+                _lib.PROFILE = {}
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    lb, _ = tr_b.step(x16, graph)
+                torch.cuda.synchronize()
+                ms_b = (time.perf_counter() - t1) / args.steps * 1e3
+                pb = _lib.profile_summary()
+                _lib.PROFILE = None
+                b1, t1_ = pb.get(f"spmm16_F{F}", (0, 0.0))
+                b2, t2_ = pb.get(f"spmm16_masked_F{F}", (0, 0.0))
+                by = nnz * 8 + (N + 1) * 4 + 2 * N * F * 2
+                tot_b, tot_t = b1 * by + b2 * (by + N * F * 2), b1 * t1_ + b2 * t2_
+                line["bf16_step"] = {"ms_per_step": ms_b, "edges_per_s": E / (ms_b * 1e-3), "steps": args.steps, "loss": float(lb.item()),
+                                     "what": "encoder activations stored as bf16, bf16 MFMA products, fp32 sums; parameters, mu|logstd, quantiser and decoder fp32",
+                                     "roofline": {"bound": "hbm", "kernel": f"ceeg_spmm_csr_cv_bf16 F={F} (aggregation + transposed pass with ReLU mask)",
+                                                  "achieved": tot_b / (tot_t * 1e-3) / 1e9 if tot_t else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": tot_b / (tot_t * 1e-3) / 1e9 / HBM_PEAK_GBS if tot_t else None, "traffic": None,
+                                                  "launches": {"aggregation": [b1, t1_], "transposed_with_relu_mask": [b2, t2_]},
+                                                  "algorithmic_bytes_per_launch": tot_b / (b1 + b2) if b1 + b2 else None}}
+
             leg("gather_only", leg_gather)
             leg("other_negatives", leg_other)
+            leg("bf16_step", leg_bf16)
             trainer = model = graph = None
             torch.cuda.empty_cache()
             # (3) BASELINE.json configs[2] (VQ 4 Mi x 512 x 256) in both dtypes and configs[3] (64 collated graphs x 100k edges)

@@ -40,6 +40,7 @@ SIGNATURES = {
     "ceeg_spmm_csr_items": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_spmm_csr_masked": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_i64, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_spmm_csr_cv": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _vp, _c_i64, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),
+    "ceeg_spmm_csr_cv_bf16": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _vp, _c_i64, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_spmm_gather_probe": (_c_int, [_vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_int, _vp, _c_sz, _vp]),
     "ceeg_reparam_kl_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_reparam_kl_fwd": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_u64, _c_i64, _c_int, _c_f32, _c_int, _c_int, _vp, _vp, _vp, _c_sz, _vp]),

@@ -217,10 +217,11 @@ struct CeegSpmmEx {
   int nt = 0;                     // bit 0: non-temporal stores of out; bit 1: non-temporal loads of the col / val streams
   const int32_t* xidx = nullptr;  // row indirection for X (after the column map): gather X[xidx[c]] - X is then a small table
   const int2* colval = nullptr;   // (col, val bits) interleaved: one 8-byte stream instead of two 4-byte ones (col / val arguments then unused)
+  int bf16 = 0;                   // X, mask and out hold bf16 (sums fp32); no accumulate / addend / table in this form
   const float* mask = nullptr;    // [N, ld_mask]: the finished row is multiplied by (mask[r, f] > 0) - a ReLU's backward mask, applied
   int64_t ld_mask = 0;            // to the gradient the pass produces (the mask row is fetched before the gathers, off the critical path)
 };
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
-                     const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
-                     int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
+                     const void* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                     int accumulate, void* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
                      const CeegSpmmEx& ex);

@@ -31,8 +31,31 @@ constexpr size_t SPMM_QUEUE_BYTES = 8 * SPMM_SUBQ * 128;  // 8 counters on 128-b
 // K consecutive steps of a batch: step i covers entries j = i*G + g of the batch (g = lane group).
 // All K gathers are issued before the first FMA (K x 1 KiB per wave in flight), the FMAs then run in
 // ascending entry order, so the summation order does not depend on K.
-template <int LPR, int K>
-__device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n, int sub, const float* __restrict__ X,
+// Row pieces: 4 consecutive features per lane, fp32 (16 bytes) or bf16 storage (8 bytes; BF = true: the gathered matrix, the
+// ReLU mask and the output are bf16, sums stay fp32 - the opt-in reduced-precision step halves the bytes of every gathered row).
+template <bool BF>
+__device__ __forceinline__ float4 spmm_load4(const void* __restrict__ base, int64_t elem) {
+  if constexpr (BF) {
+    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + elem);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+  } else {
+    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void spmm_store4(void* __restrict__ base, int64_t elem, const float4& v) {
+  if constexpr (BF) {
+    uint2 u;
+    u.x = (unsigned)ceeg_f32_to_bf16(v.x) | ((unsigned)ceeg_f32_to_bf16(v.y) << 16);
+    u.y = (unsigned)ceeg_f32_to_bf16(v.z) | ((unsigned)ceeg_f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(base) + elem) = u;
+  } else {
+    *reinterpret_cast<float4*>(static_cast<float*>(base) + elem) = v;
+  }
+}
+
+template <int LPR, int K, bool BF = false>
+__device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n, int sub, const void* __restrict__ X,
                                              int64_t ldx, int foff, bool fl_ok, float4& acc) {
   constexpr int G = 64 / LPR;
   float4 x[K];
@@ -52,7 +75,7 @@ __device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n
       ld = ld && j < n;
     }
     x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ld) x[k] = *reinterpret_cast<const float4*>(X + (int64_t)c * ldx + foff);
+    if (ld) x[k] = spmm_load4<BF>(X, (int64_t)c * ldx + foff);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -90,9 +113,9 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
 }
 
 // sum over positions [p_lo, p_hi); (my_c, my_v) hold the already-loaded first batch (positions p_lo .. p_lo+63)
-template <int LPR>
+template <int LPR, bool BF = false>
 __device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, const float* __restrict__ val,
-                                              const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx,
+                                              const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx,
                                               int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex,
                                               int my_c, float my_v) {
   constexpr int G = 64 / LPR;
@@ -103,11 +126,11 @@ __device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, c
     if (base != p_lo) load_batch(col, val, vperm, base, p_hi, lane, ex, my_c, my_v);
     const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
     int i0 = 0;
-    for (; i0 + 8 <= ns; i0 += 8) gather_steps<LPR, 8>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc);
+    for (; i0 + 8 <= ns; i0 += 8) gather_steps<LPR, 8, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc);
     const int rem = ns - i0;
-    if (rem & 4) { gather_steps<LPR, 4>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 4; }
-    if (rem & 2) { gather_steps<LPR, 2>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 2; }
-    if (rem & 1) { gather_steps<LPR, 1>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); }
+    if (rem & 4) { gather_steps<LPR, 4, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 4; }
+    if (rem & 2) { gather_steps<LPR, 2, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 2; }
+    if (rem & 1) { gather_steps<LPR, 1, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); }
   }
   if constexpr (G > 1) {
 #pragma unroll
@@ -121,14 +144,14 @@ __device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, c
   return acc;
 }
 
-template <int LPR>
+template <int LPR, bool BF = false>
 __device__ __forceinline__ float4 seg_sum(const int32_t* __restrict__ col, const float* __restrict__ val,
-                                          const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx,
+                                          const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx,
                                           int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex) {
   int my_c;
   float my_v;
   load_batch(col, val, vperm, p_lo, p_hi, lane, ex, my_c, my_v);
-  return seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, my_c, my_v);
+  return seg_sum_pre<LPR, BF>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, my_c, my_v);
 }
 
 __device__ __forceinline__ int row_of(const int32_t* __restrict__ rowptr, int64_t N, int p) {
@@ -141,10 +164,10 @@ __device__ __forceinline__ int row_of(const int32_t* __restrict__ rowptr, int64_
 }
 
 // pieces of long rows: wave w handles global positions [w*CHUNK, (w+1)*CHUNK)
-template <int LPR>
+template <int LPR, bool BF = false>
 __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
+    const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
     float* __restrict__ partial, CeegSpmmEx ex) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + (threadIdx.x >> 6);
@@ -160,21 +183,21 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_kernel(
   const int r1 = row_of(rowptr, N, p1 - 1);
   if (rowptr[r0 + 1] - rowptr[r0] > SPMM_CHUNK) {  // slot 0: the long row that covers p0
     const int e = rowptr[r0 + 1] < p1 ? rowptr[r0 + 1] : p1;
-    const float4 a = seg_sum<LPR>(col, val, vperm, X, ldx, p0, e, lane, foff, fl_ok, ex);
+    const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, p0, e, lane, foff, fl_ok, ex);
     if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + ((size_t)w * 2 + 0) * (4 * LPR) + 4 * fl) = a;
   }
   if (r1 != r0 && rowptr[r1 + 1] - rowptr[r1] > SPMM_CHUNK) {  // slot 1: a long row that starts inside
-    const float4 a = seg_sum<LPR>(col, val, vperm, X, ldx, rowptr[r1], p1, lane, foff, fl_ok, ex);
+    const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, rowptr[r1], p1, lane, foff, fl_ok, ex);
     if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + ((size_t)w * 2 + 1) * (4 * LPR) + 4 * fl) = a;
   }
 }
 
 // the same pieces from a list the caller built once per graph: item = (lo, hi, chunk*2 + slot, row); one wave per item,
 // no row search and no waves for the chunks that hold no long row (config 2's transposed graph: 3.4 k items in 66 k chunks)
-template <int LPR>
+template <int LPR, bool BF = false>
 __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_items_kernel(
     const int4* __restrict__ items, int64_t n_items, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int F, int fbase, float* __restrict__ partial,
+    const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx, int F, int fbase, float* __restrict__ partial,
     CeegSpmmEx ex) {
   const int lane = threadIdx.x & 63;
   const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + (threadIdx.x >> 6);
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_items_kernel(
   const int fl = lane % LPR;
   const int foff = fbase + 4 * fl;
   const bool fl_ok = foff < F;
-  const float4 a = seg_sum<LPR>(col, val, vperm, X, ldx, it.x, it.y, lane, foff, fl_ok, ex);
+  const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, it.x, it.y, lane, foff, fl_ok, ex);
   if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + (size_t)it.z * (4 * LPR) + 4 * fl) = a;
 }
 
@@ -206,11 +229,11 @@ __device__ __forceinline__ int64_t row_lower_bound(const int32_t* __restrict__ r
 //    tight window of live rows: time-local events re-use their gathered neighbours from that L2, and
 //    heavy rows cannot unbalance the waves.  Which wave computes a row never changes its value.
 //  Every workgroup leaves when its draw passes the end of the range (the counter only grows).
-template <int LPR>
+template <int LPR, bool BF = false>
 __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const float* __restrict__ val,
-    const int32_t* __restrict__ vperm, const float* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
-    const float* __restrict__ bias, int relu, int accumulate, float* __restrict__ out, int64_t ldo,
+    const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx, int64_t N, int F, int fbase,
+    const float* __restrict__ bias, int relu, int accumulate, void* __restrict__ out, int64_t ldo,
     const float* __restrict__ partial, unsigned int* __restrict__ queue /* 8 counters, 128 B apart, zeroed before the launch */, CeegSpmmEx ex) {
   static_assert(SPMM_GRAB == SPMM_WAVES, "one row per wave per draw");
   __shared__ unsigned int s_draw[2];
@@ -267,9 +290,9 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     if (r < r_end) {
       float4 acc;
       float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (ex.mask && lane < LPR && fl_ok) mk = *reinterpret_cast<const float4*>(ex.mask + r * ex.ld_mask + foff);  // in flight under the gathers
+      if (ex.mask && lane < LPR && fl_ok) mk = spmm_load4<BF>(ex.mask, r * ex.ld_mask + foff);  // in flight under the gathers
       if (p_hi - p_lo <= SPMM_CHUNK) {
-        acc = seg_sum_pre<LPR>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
+        acc = seg_sum_pre<LPR, BF>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
       } else {
         acc = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
@@ -296,8 +319,8 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         }
         int64_t ro = r;
         if (ex.row_a != 1 || ex.row_b != 0) ro = ceeg_block_affine(r, ex.row_a, ex.row_b, ex.mod);
-        float* o = out + ro * ldo + foff;
-        if (accumulate) {
+        float* o = BF ? nullptr : static_cast<float*>(out) + ro * ldo + foff;
+        if (!BF && accumulate) {
           const float4 t = *reinterpret_cast<const float4*>(o);
           acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
         }
@@ -308,7 +331,9 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
           acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
           acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
         }
-        if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
+        if constexpr (BF) {
+          spmm_store4<true>(out, ro * ldo + foff, acc);
+        } else if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
           __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
           __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
         } else {
@@ -334,19 +359,19 @@ int lpr_for(int F) {
   return l;
 }
 
-template <int LPR>
-int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm, const float* X,
+template <int LPR, bool BF = false>
+int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm, const void* X,
                 int64_t ldx, int64_t N, int64_t nnz, int F, int fbase, const float* bias, int relu, int accumulate,
-                float* out, int64_t ldo, float* partial, unsigned int* queue, hipStream_t st, const CeegSpmmEx& ex) {
+                void* out, int64_t ldo, float* partial, unsigned int* queue, hipStream_t st, const CeegSpmmEx& ex) {
   const int64_t nchunk = (nnz + SPMM_CHUNK - 1) / SPMM_CHUNK;
   if (nchunk > 0 && ex.long_items != nullptr) {  // the caller's piece list covers every row longer than SPMM_CHUNK
     if (ex.n_long_items > 0) {
-      hipLaunchKernelGGL(spmm_long_items_kernel<LPR>, dim3((unsigned)((ex.n_long_items + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64),
+      hipLaunchKernelGGL((spmm_long_items_kernel<LPR, BF>), dim3((unsigned)((ex.n_long_items + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64),
                          0, st, reinterpret_cast<const int4*>(ex.long_items), ex.n_long_items, col, val, vperm, X, ldx, F, fbase, partial, ex);
       CEEG_CHECK_LAUNCH();
     }
   } else if (nchunk > 0 && !(ex.max_row_nnz >= 0 && ex.max_row_nnz <= SPMM_CHUNK)) {  // skipped when the caller knows there is no long row
-    hipLaunchKernelGGL(spmm_long_kernel<LPR>, dim3((unsigned)((nchunk + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64), 0, st,
+    hipLaunchKernelGGL((spmm_long_kernel<LPR, BF>), dim3((unsigned)((nchunk + SPMM_WAVES - 1) / SPMM_WAVES)), dim3(SPMM_WAVES * 64), 0, st,
                        rowptr, col, val, vperm, X, ldx, N, F, fbase, partial, ex);
     CEEG_CHECK_LAUNCH();
   }
@@ -355,7 +380,7 @@ int launch_pass(const int32_t* rowptr, const int32_t* col, const float* val, con
   static const int bpx_cap = getenv("CEEG_SPMM_BPX") ? atoi(getenv("CEEG_SPMM_BPX")) : SPMM_BLOCKS_PER_XCD;  // tuning knob
   if (per_xcd > bpx_cap) per_xcd = bpx_cap;  // ... capped at 8 resident blocks on each of 32 CUs
   if (per_xcd < SPMM_SUBQ) per_xcd = SPMM_SUBQ;  // every interleaved sub-queue needs a workgroup that drains it (tiny graphs)
-  hipLaunchKernelGGL(spmm_rows_kernel<LPR>, dim3((unsigned)(8 * per_xcd)), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx,
+  hipLaunchKernelGGL((spmm_rows_kernel<LPR, BF>), dim3((unsigned)(8 * per_xcd)), dim3(SPMM_WAVES * 64), 0, st, rowptr, col, val, vperm, X, ldx,
                      N, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, ex);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
@@ -513,13 +538,14 @@ extern "C" size_t ceeg_spmm_ws_bytes(int64_t N, int64_t nnz, int F) {
 }
 
 int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* vperm,
-                     const float* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
-                     int accumulate, float* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
+                     const void* X, int64_t ldx, int64_t N, int64_t nnz, int F, const float* bias, int relu,
+                     int accumulate, void* out, int64_t ldo, void* ws, size_t ws_bytes, hipStream_t st,
                      const CeegSpmmEx& ex) {
   if (N <= 0 || nnz < 0 || !rowptr || !X || !out || (nnz > 0 && !ex.colval && (!col || !val))) return CEEG_EINVAL;
   if (ex.colval && (vperm || ex.xidx || ex.val_stride != 1 || ex.col_a != 1 || ex.col_b != 0 || !ceeg_aligned(ex.colval, 8))) return CEEG_EINVAL;
   if (F < 4 || F > 1024 || (F % 4) != 0 || (ldx % 4) != 0 || (ldo % 4) != 0 || ldx < F || ldo < F) return CEEG_EUNSUPPORTED;
-  if (!ceeg_aligned(X, 16) || !ceeg_aligned(out, 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
+  if (!ceeg_aligned(X, ex.bf16 ? 8 : 16) || !ceeg_aligned(out, ex.bf16 ? 8 : 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
+  if (ex.bf16 && (accumulate || ex.addend || ex.xidx || (ex.nt & 1))) return CEEG_EUNSUPPORTED;
   if (nnz >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ws_bytes < ceeg_spmm_ws_bytes(N, nnz, F) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   unsigned int* queue = static_cast<unsigned int*>(ws);
@@ -529,7 +555,8 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
   for (int fbase = 0; fbase < F && rc == CEEG_OK; fbase += 4 * lpr) {
 #define CEEG_SPMM_CASE(L)                                                                                                       \
   case L:                                                                                                                       \
-    rc = launch_pass<L>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, st, ex); \
+    rc = ex.bf16 ? launch_pass<L, true>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, st, ex) \
+                 : launch_pass<L, false>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, st, ex); \
     break;
     switch (lpr) {
       CEEG_SPMM_CASE(1)
@@ -629,6 +656,29 @@ extern "C" int ceeg_spmm_csr_cv(const int32_t* rowptr, const void* colval, const
   ex.mask = mask;
   ex.ld_mask = ld_mask;
   ex.colval = colval ? static_cast<const int2*>(colval) : &no_cv;
+  return ceeg_spmm_launch(rowptr, nullptr, nullptr, nullptr, X, ldx, N, nnz, F, bias, relu, 0, out, ldo, ws, ws_bytes,
+                          static_cast<hipStream_t>(stream), ex);
+}
+
+// The reduced-precision form of ceeg_spmm_csr_cv: X, mask and out hold bf16 (2-byte elements, row strides in elements), sums in fp32.
+extern "C" int ceeg_spmm_csr_cv_bf16(const int32_t* rowptr, const void* colval, const void* X, int64_t ldx, int64_t N, int64_t nnz, int F,
+                                     const float* bias, int relu, const void* mask, int64_t ld_mask, void* out, int64_t ldo,
+                                     int64_t max_row_nnz, const int32_t* long_items, int64_t n_long, void* ws, size_t ws_bytes, void* stream) {
+  if (!colval && nnz > 0) return CEEG_EINVAL;
+  if (mask && (ld_mask < F || (ld_mask % 4) != 0 || !ceeg_aligned(mask, 8))) return CEEG_EINVAL;
+  if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
+  if (max_row_nnz < 0 || (max_row_nnz > SPMM_CHUNK && n_long == 0)) return CEEG_EINVAL;
+  static const int32_t no_items[4] = {0, 0, 0, 0};
+  static const int2 no_cv = {0, 0};
+  CeegSpmmEx ex;
+  ex.mod = N;
+  ex.max_row_nnz = max_row_nnz;
+  ex.long_items = n_long > 0 ? long_items : no_items;
+  ex.n_long_items = n_long;
+  ex.mask = static_cast<const float*>(mask);
+  ex.ld_mask = ld_mask;
+  ex.colval = colval ? static_cast<const int2*>(colval) : &no_cv;
+  ex.bf16 = 1;
   return ceeg_spmm_launch(rowptr, nullptr, nullptr, nullptr, X, ldx, N, nnz, F, bias, relu, 0, out, ldo, ws, ws_bytes,
                           static_cast<hipStream_t>(stream), ex);
 }

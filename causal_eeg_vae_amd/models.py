@@ -159,16 +159,30 @@ class EventGraph:
         # values in the transposed order, gathered once: the backward SpMM then streams them instead of chasing
         # val[t_perm[q]] (a dependent load in front of every row's gathers)
         self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
-        self.reuse, self._gcn_cv = True, None
+        self.reuse, self._gcn_cv, self._gcn_tcv = True, None, None
+
+    def cv(self, transposed=False):
+        """(column, value) pairs of the normalised adjacency (or its transpose) interleaved into one int32 [nnz, 2] stream."""
+        if transposed:
+            if self._gcn_tcv is None:
+                self._gcn_tcv = torch.stack([self.gcn.t_col, self.gcn_tval.view(torch.int32)], dim=1).contiguous()
+            return self._gcn_tcv
+        if self._gcn_cv is None:
+            self._gcn_cv = torch.stack([self.gcn.col, self.gcn_val.view(torch.int32)], dim=1).contiguous()
+        return self._gcn_cv
+
+    def aggregate16(self, h, transposed=False, mask=None):
+        """A_hat @ h (transposed: A_hat^T @ h, optionally times (mask > 0)) with bf16 storage and fp32 sums."""
+        g = self.gcn
+        rp, mr, items = (g.t_rowptr, g.max_trow, g.long_items(True)) if transposed else (g.rowptr, g.max_row, g.long_items(False))
+        return _spmm_cv(rp, self.cv(transposed), h.contiguous(), self.num_nodes, g.nnz, mask=mask, max_row=mr, items=items)
 
     def aggregate(self, h, bias=None, relu=False):
         """act(A_hat @ h + b).  A graph that is reused across steps (`reuse`, the default; a minibatch-stream graph is not)
         keeps its (column, value) pairs interleaved in one stream (built on first use): 7 % off the F = 128 launch."""
         g = self.gcn
         if self.reuse and g.nnz and os.environ.get("CEEG_SPMM_CV", "1") == "1":
-            if self._gcn_cv is None:
-                self._gcn_cv = torch.stack([g.col, self.gcn_val.view(torch.int32)], dim=1).contiguous()
-            return _spmm_cv(g.rowptr, self._gcn_cv, h, self.num_nodes, g.nnz, bias=bias, relu=relu, max_row=g.max_row, items=g.long_items(False))
+            return _spmm_cv(g.rowptr, self.cv(False), h, self.num_nodes, g.nnz, bias=bias, relu=relu, max_row=g.max_row, items=g.long_items(False))
         return _spmm(g.rowptr, g.col, self.gcn_val, None, h, self.num_nodes, bias=bias, relu=relu, max_row=g.max_row, items=g.long_items(False))
 
     def edge_index_i32(self):
@@ -194,8 +208,17 @@ def _spmm_cv(rowptr, colval, x, n_rows, nnz, bias=None, relu=False, mask=None, m
     """ceeg_spmm_csr_cv: the aggregation over a CSR whose (column, value) pairs are interleaved into one 8-byte stream."""
     L = _lib.lib()
     F = x.shape[1]
-    out = torch.empty(n_rows, F, dtype=torch.float32, device=x.device)
+    out = torch.empty(n_rows, F, dtype=x.dtype, device=x.device)
     ws = _lib.workspace(L.ceeg_spmm_ws_bytes(n_rows, nnz, F), x.device)
+    if x.dtype == torch.bfloat16:   # bf16 storage of the gathered matrix, the mask and the result; fp32 sums
+        if mask is not None and mask.dtype != torch.bfloat16:
+            raise ValueError("the bf16 aggregation takes a bf16 mask")
+        with _lib.timed(f"spmm16_masked_F{F}" if mask is not None else f"spmm16_F{F}"):
+            _lib.check(L.ceeg_spmm_csr_cv_bf16(rowptr.data_ptr(), colval.data_ptr(), x.data_ptr(), x.stride(0), n_rows, nnz, F, _lib.ptr(bias), int(relu),
+                                               _lib.ptr(mask), 0 if mask is None else mask.stride(0), out.data_ptr(), out.stride(0), int(max_row),
+                                               _lib.ptr(items), 0 if items is None else items.shape[0], ws.data_ptr(), ws.numel(), _lib.stream()),
+                       "ceeg_spmm_csr_cv_bf16")
+        return out
     with _lib.timed(f"spmm_masked_F{F}" if mask is not None else f"spmm_F{F}"):
         _lib.check(L.ceeg_spmm_csr_cv(rowptr.data_ptr(), colval.data_ptr(), x.data_ptr(), x.stride(0), n_rows, nnz, F, _lib.ptr(bias), int(relu),
                                       _lib.ptr(mask), 0 if mask is None else mask.stride(0), out.data_ptr(), out.stride(0), int(max_row),
@@ -387,6 +410,101 @@ class _LinearReluAggregate(torch.autograd.Function):
         dw = _weight_grad(ax, gm) if ctx.needs_input_grad[1] else None
         dax = torch.mm(gm, weight) if ctx.needs_input_grad[0] else None
         return dax, dw, db, None
+
+
+# ---- opt-in reduced-precision encoder (bf16 storage and bf16 MFMA products, fp32 accumulation everywhere) -------------------------
+_F32_OUT = {}
+
+
+def _mm16(a, b, bias=None):
+    """fp32 result of a bf16 product (+ fp32 bias): the library's fp32-output form where this PyTorch build has it (no rounding
+    of the accumulator), else the bf16 product widened."""
+    mode = _F32_OUT.get("mm")
+    if mode is None:
+        try:
+            torch.mm(a[:1], b, out_dtype=torch.float32)
+            mode = True
+        except Exception:   # noqa: BLE001 - an older / different build: fall back
+            mode = False
+        _F32_OUT["mm"] = mode
+    y = torch.mm(a, b, out_dtype=torch.float32) if mode else torch.mm(a, b).float()
+    return y if bias is None else y.add_(bias)
+
+
+def _weight_grad16(x, g):
+    """dW = g^T x (fp32 [out, in]) for bf16 x [N, in], g [N, out]: split over K as _weight_grad, the per-slice products leave the
+    matrix cores in fp32 where the build allows, and are summed in fp32 in a fixed order."""
+    n = x.shape[0]
+    s = _split_k(n)
+    xs, gs = x.contiguous().view(s, n // s, -1).transpose(1, 2), g.contiguous().view(s, n // s, -1)
+    mode = _F32_OUT.get("bmm")
+    if mode is None:
+        try:
+            torch.bmm(xs[:1, :, :1], gs[:1, :1], out_dtype=torch.float32)
+            mode = True
+        except Exception:   # noqa: BLE001
+            mode = False
+        _F32_OUT["bmm"] = mode
+    part = torch.bmm(xs, gs, out_dtype=torch.float32) if mode else torch.bmm(xs, gs).float()
+    return part.sum(dim=0).t()
+
+
+class _LinearReluAggregate16(torch.autograd.Function):
+    """_LinearReluAggregate on bf16 activations: h = relu(ax W^T + b) from the bf16 MFMA GEMM (bias + ReLU epilogue), ah = A_hat h
+    gathered as 512-byte rows; backward: gm = (A_hat^T dah) * (h > 0) in one pass, db = column sums (fp32), dW = gm^T ax."""
+
+    @staticmethod
+    def forward(ctx, ax, weight, bias, graph):
+        w16 = weight.detach().to(torch.bfloat16)
+        h = torch._addmm_activation(bias.detach().to(torch.bfloat16), ax, w16.t().contiguous())
+        ah = graph.aggregate16(h)
+        ctx.save_for_backward(ax, h)
+        ctx.graph = graph
+        return ah
+
+    @staticmethod
+    def backward(ctx, dah):
+        ax, h = ctx.saved_tensors
+        gm = ctx.graph.aggregate16(dah.contiguous(), transposed=True, mask=h)
+        db = torch.sum(gm, dim=0, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        dw = _weight_grad16(ax, gm) if ctx.needs_input_grad[1] else None
+        return None, dw, db, None
+
+
+class _HeadReparamVQ16(torch.autograd.Function):
+    """_HeadReparamVQ with the head product on bf16 operands: ml = ah W^T + b leaves the GEMM in fp32 (mu | logstd, the noise and
+    the quantiser stay fp32 - the codes decide the decoder's gathers); backward: dml (fp32, from the fused kernel) is rounded to
+    bf16 once for the two products dah = dml W and dW = dml^T ah; the bias gradient is the fused kernel's fp32 column sums."""
+
+    @staticmethod
+    def forward(ctx, ah, wcat, bcat, eps, seed, training, log_var, weight, beta):
+        _lib.require_cuda(ah, weight)
+        w16 = wcat.detach().to(torch.bfloat16)
+        ml = _mm16(ah, w16.t().contiguous(), bcat.detach())
+        z, kl, scal, z_q, idx, epsc, wc = _rvq_forward(ml, eps, seed, training, log_var, weight, beta)
+        ctx.save_for_backward(ah, w16, ml, epsc, wc, idx, z)
+        ctx.cfg = (int(seed), int(training), int(log_var), float(beta))
+        loss_t, ppl_t = scal[0], scal[1]
+        ctx.mark_non_differentiable(ppl_t, idx)
+        ctx.set_materialize_grads(False)
+        return ml, z, kl, loss_t, z_q, ppl_t, idx
+
+    @staticmethod
+    def backward(ctx, g_ml, g_z, g_kl, g_loss, g_zq, _g_ppl, _g_idx):
+        ah, w16, ml, epsc, wc, idx, z = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dml, colsum, dW = _rvq_backward(ml, epsc, wc, idx, z, ctx.cfg, g_z, g_kl, g_loss, g_zq, need[7], need[0] or need[1] or need[2],
+                                        need[2] and g_ml is None)
+        dah = dwcat = dbcat = None
+        if dml is not None:
+            if g_ml is not None:
+                dml = dml + g_ml
+                colsum = _colsum(dml) if need[2] else None
+            dbcat = colsum
+            d16 = dml.to(torch.bfloat16)
+            dwcat = _weight_grad16(ah, d16) if need[1] else None
+            dah = torch.mm(d16, w16) if need[0] else None
+        return dah, dwcat, dbcat, None, None, None, None, dW, None
 
 
 class _Lin(nn.Module):
@@ -1011,8 +1129,11 @@ class VariationalGCNEncoder(nn.Module):
     """2-layer variational GCN encoder (PyG example convention): conv1 F_in -> 2*latent (ReLU),
     conv_mu / conv_logstd 2*latent -> latent.  The two heads run as ONE SpMM over h @ [W_mu | W_sigma]^T."""
 
-    def __init__(self, in_channels, latent):
+    def __init__(self, in_channels, latent, compute_dtype=torch.float32):
         super().__init__()
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute_dtype must be torch.float32 or torch.bfloat16")
+        self.compute_dtype = compute_dtype
         self.conv1 = GCNConv(in_channels, 2 * latent, aggregate_first=in_channels < 2 * latent)
         self.conv_mu = GCNConv(2 * latent, latent)
         self.conv_logstd = GCNConv(2 * latent, latent)
@@ -1036,6 +1157,18 @@ class VariationalGCNEncoder(nn.Module):
         reparametrise + quantiser with the head's bias gradient a real output of the fused backward - the same arithmetic
         re-associated: (A_hat h) W^T + b == A_hat (h W^T) + b.  CEEG_FUSED_HEAD=0 keeps the layer-by-layer form (the checker)."""
         D = self.latent
+        if self.compute_dtype == torch.bfloat16:
+            # opt-in reduced precision (north star: "rtol 1e-2 (bf16)"): activations stored as bf16 - every gathered row is half
+            # the bytes -, dense products on the bf16 matrix cores, fp32 accumulation throughout; parameters, mu | logstd, the
+            # noise, the quantiser and the decoder stay fp32.  Pass x already as bf16 to keep its conversion out of the step.
+            if not self.conv1.aggregate_first or D % 4 or x.shape[1] % 4:
+                raise ValueError("the bf16 encoder needs in_channels < 2 * latent and widths that are multiples of 4")
+            with torch.no_grad():
+                ax = graph.aggregate16(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
+            ah = _LinearReluAggregate16.apply(ax, self.conv1.lin.weight, self.conv1.bias, graph)
+            wcat = torch.cat([self.conv_mu.lin.weight, self.conv_logstd.lin.weight], dim=0)
+            bcat = torch.cat([self.conv_mu.bias, self.conv_logstd.bias], dim=0)
+            return _HeadReparamVQ16.apply(ah, wcat, bcat, eps, seed, training, False, vq.embedding.weight, vq.beta)
         if (self.conv1.aggregate_first and D % 4 == 0 and os.environ.get("CEEG_FUSED_RVQ", "1") == "1"
                 and os.environ.get("CEEG_FUSED_HEAD", "1") == "1"):
             ax = _GcnAggregate.apply(x, None, graph, False)
@@ -1099,7 +1232,7 @@ class VGAEVQ(nn.Module):
         loss = rec + kl / N + vq_loss                                   (loss sum as scripts/run.py:95)
     """
 
-    def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0, negatives="sigma"):
+    def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0, negatives="sigma", compute_dtype=torch.float32):
         """negatives: "sigma" = permutation-structured negatives (col[p], sigma(r)) drawn inside the fused decoder (no per-step
         sort; colliding pairs masked) - the fast path; "uniform" = the literal recon_loss path: E pairs from
         negative_sampling (ceeg_neg_sample_uniform, rejection against the edge set) decoded through the edge-list kernel,
@@ -1107,7 +1240,7 @@ class VGAEVQ(nn.Module):
         super().__init__()
         if negatives not in ("sigma", "uniform"):
             raise ValueError("negatives must be 'sigma' or 'uniform'")
-        self.encoder = VariationalGCNEncoder(in_channels, latent)
+        self.encoder = VariationalGCNEncoder(in_channels, latent, compute_dtype)
         self.vector_quantization = VectorQuantizer(num_latent_embeddings, latent, beta, return_one_hot=False)
         self.latent, self.seed, self.negatives = latent, int(seed), negatives
 

@@ -186,6 +186,14 @@ int ceeg_spmm_csr_cv(const int32_t* rowptr, const void* colval, const float* X, 
                      const float* bias, int relu, const float* mask, int64_t ld_mask, float* out, int64_t ldo,
                      int64_t max_row_nnz, const int32_t* long_items, int64_t n_long, void* ws, size_t ws_bytes, void* stream);
 
+/* ceeg_spmm_csr_cv with bf16 STORAGE (the opt-in reduced-precision step; no reference counterpart - north star: "rtol 1e-2
+ * (bf16)"): X, mask and out hold bf16 (2-byte elements, ldx / ld_mask / ldo in elements, 8-byte aligned rows), every sum is
+ * accumulated in fp32 in the order of the fp32 form and rounded to nearest-even once, on the store.  A gathered row is half the
+ * bytes: the far-entry fetch that bounds the fp32 aggregation halves. */
+int ceeg_spmm_csr_cv_bf16(const int32_t* rowptr, const void* colval, const void* X, int64_t ldx, int64_t N, int64_t nnz, int F,
+                          const float* bias, int relu, const void* mask, int64_t ld_mask, void* out, int64_t ldo,
+                          int64_t max_row_nnz, const int32_t* long_items, int64_t n_long, void* ws, size_t ws_bytes, void* stream);
+
 /* ceeg_spmm_csr whose gathered matrix is a TABLE read through a row index: out[i,:] (+)= sum_p v(p) * table[xidx[col[p]], :].
  * For a quantised latent (z[n] = codebook[code[n]] bit for bit) this is the same sum as gathering z itself - bitwise equal -
  * with the rows coming from a few hundred KB that stay in L2 (the backward of the edge-list decoder over sampled negatives). */

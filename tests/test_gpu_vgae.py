@@ -988,3 +988,54 @@ def test_minibatch_stream_construction_equals_static_graph():
     l3, g3, _ = run(g_bad, cb2.batch)
     l4, g4, _ = run(EventGraph(cb2.edge_index, cb2.num_nodes), cb2.batch)
     assert torch.equal(l3, l4) and all(torch.equal(a, b) for a, b in zip(g3, g4))
+
+
+@pytest.mark.parametrize("negatives", ["sigma", "uniform"])
+def test_bf16_step_vs_oracle_at_bf16_tolerance(negatives):
+    """The opt-in reduced-precision step (VGAEVQ(compute_dtype=torch.bfloat16): bf16 storage of the encoder's activations, bf16
+    MFMA products, fp32 sums, fp32 quantiser / decoder) against the fp64 oracle on the same fp32 inputs, at the north star's
+    bf16 tolerance: rtol 1e-2 with the absolute floor 1e-2 max|ref| for gradients (a gradient entry is a long sum of rounded
+    terms) - loss terms, latent, every parameter gradient.  The bf16 noise on z (~0.4 % per rounding) moves rows across
+    near-by code boundaries: every flipped row's exact distance to the GPU's code must be within 3 % of the row's scale of the
+    minimum, and losses / gradients are then compared with the GPU's codes forced.  Two runs are bitwise identical."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
+    from oracle import c_oracle, ref_torch
+    N, E, Fi, D, n_e = 4000, 64000, 16, 16, 64
+    ei_np = _graph(N, E, 2)
+    torch.manual_seed(0)
+    ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = VGAEVQ(Fi, D, n_e, 0.25, seed=3, negatives=negatives, compute_dtype=torch.bfloat16).cuda()
+    model.load_state_dict(ref.state_dict())
+    x, eps = torch.randn(N, Fi), torch.randn(N, D)
+    ei = torch.from_numpy(ei_np)
+    g = EventGraph(ei.cuda(), N)
+    rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+    if negatives == "sigma":
+        sig = sigma_params(N, 0, 5)
+        s, sg, valid = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1])
+        neg_ei, valid_t, kw = torch.from_numpy(np.stack([s, sg]).astype(np.int64)), torch.from_numpy(valid), dict(sigma=sig)
+    else:
+        s, d = c_oracle.neg_sample_uniform(rowptr, col, N, E, model.negative_seed(5))
+        neg_ei, valid_t, kw = torch.from_numpy(np.stack([s, d]).astype(np.int64)), None, {}
+    runs = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        loss, aux = model(x.cuda().to(torch.bfloat16), g, step=5, eps=eps.cuda(), **kw)
+        loss.backward()
+        runs.append((loss.detach().clone(), aux["idx"].clone(), [p.grad.clone() for p in model.parameters()]))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    ref64 = to64(ref)
+    with torch.no_grad():
+        _, aux0 = ref64(x.double(), ei, eps.double(), neg_ei, valid_t)
+    _close(aux["z"], aux0["z"], rtol=1e-2, atol_rel=1e-2)
+    n_flip = flipped_rows_are_near_ties(aux["idx"], ref64.vector_quantization, bound_rel=3e-2)
+    assert n_flip < N // 4
+    loss_ref, aux_ref = ref64(x.double(), ei, eps.double(), neg_ei, valid_t, force_idx=aux["idx"].cpu())
+    loss_ref.backward()
+    for k in ("kl", "rec", "vq"):
+        _close(aux[k], aux_ref[k], rtol=1e-2, atol_rel=1e-2, what=k)
+    _close(loss, loss_ref, rtol=1e-2, atol_rel=1e-2)
+    grads_close(model, ref64, rtol=1e-2, atol_rel=1e-2)
