@@ -31,34 +31,81 @@ constexpr size_t SPMM_QUEUE_BYTES = 8 * SPMM_SUBQ * 128;  // 8 counters on 128-b
 // K consecutive steps of a batch: step i covers entries j = i*G + g of the batch (g = lane group).
 // All K gathers are issued before the first FMA (K x 1 KiB per wave in flight), the FMAs then run in
 // ascending entry order, so the summation order does not depend on K.
-// Row pieces: 4 consecutive features per lane, fp32 (16 bytes) or bf16 storage (8 bytes; BF = true: the gathered matrix, the
-// ReLU mask and the output are bf16, sums stay fp32 - the opt-in reduced-precision step halves the bytes of every gathered row).
+// Row pieces: every lane owns 16 BYTES of a feature row - 4 fp32 features, or 8 features of bf16 storage (BF = true: the gathered
+// matrix, the ReLU mask and the output hold bf16, sums stay fp32; a row is half the bytes AND half the lanes, so a wave
+// instruction gathers twice as many rows - the opt-in reduced-precision step).  SpAcc<BF> = the lane's 4 / 8 running sums.
 template <bool BF>
-__device__ __forceinline__ float4 spmm_load4(const void* __restrict__ base, int64_t elem) {
-  if constexpr (BF) {
-    const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + elem);
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
-  } else {
-    return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + elem);
-  }
+struct SpAcc {
+  float4 a;
+};
+template <>
+struct SpAcc<true> {
+  float4 a, b;
+};
+template <bool BF>
+constexpr int sp_epl() { return BF ? 8 : 4; }  // elements per lane
+template <bool BF>
+__device__ __forceinline__ SpAcc<BF> sp_zero() {
+  SpAcc<BF> r;
+  r.a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (BF) r.b = r.a;
+  return r;
 }
 template <bool BF>
-__device__ __forceinline__ void spmm_store4(void* __restrict__ base, int64_t elem, const float4& v) {
-  if constexpr (BF) {
-    uint2 u;
-    u.x = (unsigned)ceeg_f32_to_bf16(v.x) | ((unsigned)ceeg_f32_to_bf16(v.y) << 16);
-    u.y = (unsigned)ceeg_f32_to_bf16(v.z) | ((unsigned)ceeg_f32_to_bf16(v.w) << 16);
-    *reinterpret_cast<uint2*>(static_cast<unsigned short*>(base) + elem) = u;
-  } else {
-    *reinterpret_cast<float4*>(static_cast<float*>(base) + elem) = v;
-  }
+__device__ __forceinline__ uint4 sp_load_raw(const void* __restrict__ base, int64_t elem) {
+  return *reinterpret_cast<const uint4*>(static_cast<const char*>(base) + elem * (BF ? 2 : 4));
 }
+template <bool BF>
+__device__ __forceinline__ SpAcc<BF> sp_unpack(const uint4& u) {
+  SpAcc<BF> r;
+  if constexpr (BF) {
+    r.a = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    r.b = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+  } else {
+    r.a = make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+  }
+  return r;
+}
+__device__ __forceinline__ void sp_fma4(float v, const float4& x, float4& acc) {
+  acc.x = __fmaf_rn(v, x.x, acc.x);
+  acc.y = __fmaf_rn(v, x.y, acc.y);
+  acc.z = __fmaf_rn(v, x.z, acc.z);
+  acc.w = __fmaf_rn(v, x.w, acc.w);
+}
+template <bool BF>
+__device__ __forceinline__ void sp_fma(float v, const uint4& raw, SpAcc<BF>& acc) {
+  const SpAcc<BF> x = sp_unpack<BF>(raw);
+  sp_fma4(v, x.a, acc.a);
+  if constexpr (BF) sp_fma4(v, x.b, acc.b);
+}
+__device__ __forceinline__ void sp_add4(float4& d, const float4& s) { d.x += s.x; d.y += s.y; d.z += s.z; d.w += s.w; }
+template <bool BF>
+__device__ __forceinline__ void sp_add(SpAcc<BF>& d, const SpAcc<BF>& s) {
+  sp_add4(d.a, s.a);
+  if constexpr (BF) sp_add4(d.b, s.b);
+}
+__device__ __forceinline__ float4 sp_xor4(const float4& v, int o) {
+  return make_float4(__shfl_xor(v.x, o, 64), __shfl_xor(v.y, o, 64), __shfl_xor(v.z, o, 64), __shfl_xor(v.w, o, 64));
+}
+template <bool BF>
+__device__ __forceinline__ SpAcc<BF> sp_load_f32(const float* __restrict__ p) {  // 4 / 8 consecutive floats (partials, bias)
+  SpAcc<BF> r;
+  r.a = *reinterpret_cast<const float4*>(p);
+  if constexpr (BF) r.b = *reinterpret_cast<const float4*>(p + 4);
+  return r;
+}
+template <bool BF>
+__device__ __forceinline__ void sp_store_f32(float* __restrict__ p, const SpAcc<BF>& v) {
+  *reinterpret_cast<float4*>(p) = v.a;
+  if constexpr (BF) *reinterpret_cast<float4*>(p + 4) = v.b;
+}
+__device__ __forceinline__ unsigned sp_pack2(float lo, float hi) { return (unsigned)ceeg_f32_to_bf16(lo) | ((unsigned)ceeg_f32_to_bf16(hi) << 16); }
 
 template <int LPR, int K, bool BF = false>
 __device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n, int sub, const void* __restrict__ X,
-                                             int64_t ldx, int foff, bool fl_ok, float4& acc) {
+                                             int64_t ldx, int foff, bool fl_ok, SpAcc<BF>& acc) {
   constexpr int G = 64 / LPR;
-  float4 x[K];
+  uint4 x[K];
   float v[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -74,18 +121,15 @@ __device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n
       v[k] = __shfl(my_v, j, 64);
       ld = ld && j < n;
     }
-    x[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ld) x[k] = spmm_load4<BF>(X, (int64_t)c * ldx + foff);
+    x[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (ld) x[k] = sp_load_raw<BF>(X, (int64_t)c * ldx + foff);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if constexpr (G > 1) {
       if (!(i0 + k < (n + G - 1) / G && (i0 + k) * G + sub < n)) continue;  // lanes past the batch end add nothing
     }
-    acc.x = __fmaf_rn(v[k], x[k].x, acc.x);
-    acc.y = __fmaf_rn(v[k], x[k].y, acc.y);
-    acc.z = __fmaf_rn(v[k], x[k].z, acc.z);
-    acc.w = __fmaf_rn(v[k], x[k].w, acc.w);
+    sp_fma<BF>(v[k], x[k], acc);
   }
 }
 
@@ -114,13 +158,13 @@ __device__ __forceinline__ void load_batch(const int32_t* __restrict__ col, cons
 
 // sum over positions [p_lo, p_hi); (my_c, my_v) hold the already-loaded first batch (positions p_lo .. p_lo+63)
 template <int LPR, bool BF = false>
-__device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, const float* __restrict__ val,
+__device__ __forceinline__ SpAcc<BF> seg_sum_pre(const int32_t* __restrict__ col, const float* __restrict__ val,
                                               const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx,
                                               int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex,
                                               int my_c, float my_v) {
   constexpr int G = 64 / LPR;
   const int sub = lane / LPR;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  SpAcc<BF> acc = sp_zero<BF>();
   for (int base = p_lo; base < p_hi; base += 64) {
     const int n = p_hi - base < 64 ? p_hi - base : 64;
     if (base != p_lo) load_batch(col, val, vperm, base, p_hi, lane, ex, my_c, my_v);
@@ -135,17 +179,15 @@ __device__ __forceinline__ float4 seg_sum_pre(const int32_t* __restrict__ col, c
   if constexpr (G > 1) {
 #pragma unroll
     for (int o = 32; o >= LPR; o >>= 1) {
-      acc.x += __shfl_xor(acc.x, o, 64);
-      acc.y += __shfl_xor(acc.y, o, 64);
-      acc.z += __shfl_xor(acc.z, o, 64);
-      acc.w += __shfl_xor(acc.w, o, 64);
+      sp_add4(acc.a, sp_xor4(acc.a, o));
+      if constexpr (BF) sp_add4(acc.b, sp_xor4(acc.b, o));
     }
   }
   return acc;
 }
 
 template <int LPR, bool BF = false>
-__device__ __forceinline__ float4 seg_sum(const int32_t* __restrict__ col, const float* __restrict__ val,
+__device__ __forceinline__ SpAcc<BF> seg_sum(const int32_t* __restrict__ col, const float* __restrict__ val,
                                           const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx,
                                           int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex) {
   int my_c;
@@ -176,19 +218,20 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_kernel(
   if (p0l >= nnz) return;
   const int p0 = (int)p0l;
   const int p1 = p0 + SPMM_CHUNK < nnz ? p0 + SPMM_CHUNK : nnz;
+  constexpr int EPL = sp_epl<BF>();
   const int fl = lane % LPR;
-  const int foff = fbase + 4 * fl;
+  const int foff = fbase + EPL * fl;
   const bool fl_ok = foff < F;
   const int r0 = row_of(rowptr, N, p0);
   const int r1 = row_of(rowptr, N, p1 - 1);
   if (rowptr[r0 + 1] - rowptr[r0] > SPMM_CHUNK) {  // slot 0: the long row that covers p0
     const int e = rowptr[r0 + 1] < p1 ? rowptr[r0 + 1] : p1;
-    const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, p0, e, lane, foff, fl_ok, ex);
-    if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + ((size_t)w * 2 + 0) * (4 * LPR) + 4 * fl) = a;
+    const SpAcc<BF> a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, p0, e, lane, foff, fl_ok, ex);
+    if (lane < LPR && fl_ok) sp_store_f32<BF>(partial + ((size_t)w * 2 + 0) * (EPL * LPR) + EPL * fl, a);
   }
   if (r1 != r0 && rowptr[r1 + 1] - rowptr[r1] > SPMM_CHUNK) {  // slot 1: a long row that starts inside
-    const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, rowptr[r1], p1, lane, foff, fl_ok, ex);
-    if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + ((size_t)w * 2 + 1) * (4 * LPR) + 4 * fl) = a;
+    const SpAcc<BF> a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, rowptr[r1], p1, lane, foff, fl_ok, ex);
+    if (lane < LPR && fl_ok) sp_store_f32<BF>(partial + ((size_t)w * 2 + 1) * (EPL * LPR) + EPL * fl, a);
   }
 }
 
@@ -203,11 +246,12 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_long_items_kernel(
   const int64_t w = (int64_t)blockIdx.x * SPMM_WAVES + (threadIdx.x >> 6);
   if (w >= n_items) return;
   const int4 it = items[w];
+  constexpr int EPL = sp_epl<BF>();
   const int fl = lane % LPR;
-  const int foff = fbase + 4 * fl;
+  const int foff = fbase + EPL * fl;
   const bool fl_ok = foff < F;
-  const float4 a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, it.x, it.y, lane, foff, fl_ok, ex);
-  if (lane < LPR && fl_ok) *reinterpret_cast<float4*>(partial + (size_t)it.z * (4 * LPR) + 4 * fl) = a;
+  const SpAcc<BF> a = seg_sum<LPR, BF>(col, val, vperm, X, ldx, it.x, it.y, lane, foff, fl_ok, ex);
+  if (lane < LPR && fl_ok) sp_store_f32<BF>(partial + (size_t)it.z * (EPL * LPR) + EPL * fl, a);
 }
 
 // first row r in [0, N] with rowptr[r] >= target
@@ -243,8 +287,9 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
   const int64_t nnz = rowptr[N];
   const int64_t r_begin = xcd == 0 ? 0 : row_lower_bound(rowptr, N, nnz * xcd / 8);
   const int64_t r_end = xcd == 7 ? N : row_lower_bound(rowptr, N, nnz * (xcd + 1) / 8);
+  constexpr int EPL = sp_epl<BF>();
   const int fl = lane % LPR;
-  const int foff = fbase + 4 * fl;
+  const int foff = fbase + EPL * fl;
   const bool fl_ok = foff < F;
   const int subq = (blockIdx.x >> 3) % SPMM_SUBQ;
   unsigned int* q = queue + (xcd * SPMM_SUBQ + subq) * 32;
@@ -288,56 +333,59 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     // gather + store the current row
     const int64_t r = base_cur + wave;
     if (r < r_end) {
-      float4 acc;
-      float4 mk = make_float4(1.f, 1.f, 1.f, 1.f);
-      if (ex.mask && lane < LPR && fl_ok) mk = spmm_load4<BF>(ex.mask, r * ex.ld_mask + foff);  // in flight under the gathers
+      SpAcc<BF> acc;
+      uint4 mk_raw = make_uint4(0u, 0u, 0u, 0u);
+      if (ex.mask && lane < LPR && fl_ok) mk_raw = sp_load_raw<BF>(ex.mask, r * ex.ld_mask + foff);  // in flight under the gathers
       if (p_hi - p_lo <= SPMM_CHUNK) {
         acc = seg_sum_pre<LPR, BF>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
       } else {
-        acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc = sp_zero<BF>();
         const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
         if (lane < LPR && fl_ok) {
           for (int c = c_lo; c <= c_hi; ++c) {  // pieces in ascending position order
             const int slot = (c == c_lo && p_lo != c * SPMM_CHUNK) ? 1 : 0;
-            const float4 a = *reinterpret_cast<const float4*>(partial + ((size_t)c * 2 + slot) * (4 * LPR) + 4 * fl);
-            acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+            sp_add<BF>(acc, sp_load_f32<BF>(partial + ((size_t)c * 2 + slot) * (EPL * LPR) + EPL * fl));
           }
         }
       }
       if (lane < LPR && fl_ok) {
-        if (ex.addend) {
-          const float4 a = *reinterpret_cast<const float4*>(ex.addend + r * ex.ld_add + foff);
-          acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        if constexpr (!BF) {  // the decoder backward's extras exist in the fp32 form only (ceeg_spmm_launch refuses them for bf16)
+          if (ex.addend) sp_add4(acc.a, *reinterpret_cast<const float4*>(ex.addend + r * ex.ld_add + foff));
+          if (ex.scale) {
+            const float sc = ex.scale[0];
+            acc.a.x *= sc; acc.a.y *= sc; acc.a.z *= sc; acc.a.w *= sc;
+          }
         }
-        if (ex.scale) {
-          const float sc = ex.scale[0];
-          acc.x *= sc; acc.y *= sc; acc.z *= sc; acc.w *= sc;
-        }
-        if (bias) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + foff);
-          acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w;
-        }
+        if (bias) sp_add<BF>(acc, sp_load_f32<BF>(bias + foff));
         int64_t ro = r;
         if (ex.row_a != 1 || ex.row_b != 0) ro = ceeg_block_affine(r, ex.row_a, ex.row_b, ex.mod);
-        float* o = BF ? nullptr : static_cast<float*>(out) + ro * ldo + foff;
-        if (!BF && accumulate) {
-          const float4 t = *reinterpret_cast<const float4*>(o);
-          acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+        if constexpr (!BF) {
+          if (accumulate) sp_add4(acc.a, *reinterpret_cast<const float4*>(static_cast<const float*>(out) + ro * ldo + foff));
         }
+        auto relu4 = [](float4& v) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); };
+        auto mask4 = [](float4& v, const float4& m) {  // g * (y > 0): exactly what ceeg_relu_bwd_colsum writes
+          v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f; v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        };
         if (relu) {
-          acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f);
+          relu4(acc.a);
+          if constexpr (BF) relu4(acc.b);
         }
-        if (ex.mask) {  // g * (y > 0): exactly what ceeg_relu_bwd_colsum writes
-          acc.x = mk.x > 0.f ? acc.x : 0.f; acc.y = mk.y > 0.f ? acc.y : 0.f;
-          acc.z = mk.z > 0.f ? acc.z : 0.f; acc.w = mk.w > 0.f ? acc.w : 0.f;
+        if (ex.mask) {
+          const SpAcc<BF> mk = sp_unpack<BF>(mk_raw);
+          mask4(acc.a, mk.a);
+          if constexpr (BF) mask4(acc.b, mk.b);
         }
-        if constexpr (BF) {
-          spmm_store4<true>(out, ro * ldo + foff, acc);
-        } else if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
-          __builtin_nontemporal_store(acc.x, o); __builtin_nontemporal_store(acc.y, o + 1);
-          __builtin_nontemporal_store(acc.z, o + 2); __builtin_nontemporal_store(acc.w, o + 3);
+        if constexpr (BF) {  // rounded to nearest-even once, on the store
+          const uint4 u = make_uint4(sp_pack2(acc.a.x, acc.a.y), sp_pack2(acc.a.z, acc.a.w), sp_pack2(acc.b.x, acc.b.y), sp_pack2(acc.b.z, acc.b.w));
+          *reinterpret_cast<uint4*>(static_cast<unsigned short*>(out) + ro * ldo + foff) = u;
         } else {
-          *reinterpret_cast<float4*>(o) = acc;
+          float* o = static_cast<float*>(out) + ro * ldo + foff;
+          if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
+            __builtin_nontemporal_store(acc.a.x, o); __builtin_nontemporal_store(acc.a.y, o + 1);
+            __builtin_nontemporal_store(acc.a.z, o + 2); __builtin_nontemporal_store(acc.a.w, o + 3);
+          } else {
+            *reinterpret_cast<float4*>(o) = acc.a;
+          }
         }
       }
     }
@@ -352,8 +400,8 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
   }
 }
 
-int lpr_for(int F) {
-  const int need = (F + 3) / 4;
+int lpr_for(int F, int epl = 4) {
+  const int need = (F + epl - 1) / epl;
   int l = 1;
   while (l < need && l < 64) l <<= 1;
   return l;
@@ -544,15 +592,17 @@ int ceeg_spmm_launch(const int32_t* rowptr, const int32_t* col, const float* val
   if (N <= 0 || nnz < 0 || !rowptr || !X || !out || (nnz > 0 && !ex.colval && (!col || !val))) return CEEG_EINVAL;
   if (ex.colval && (vperm || ex.xidx || ex.val_stride != 1 || ex.col_a != 1 || ex.col_b != 0 || !ceeg_aligned(ex.colval, 8))) return CEEG_EINVAL;
   if (F < 4 || F > 1024 || (F % 4) != 0 || (ldx % 4) != 0 || (ldo % 4) != 0 || ldx < F || ldo < F) return CEEG_EUNSUPPORTED;
-  if (!ceeg_aligned(X, ex.bf16 ? 8 : 16) || !ceeg_aligned(out, ex.bf16 ? 8 : 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
+  if (!ceeg_aligned(X, 16) || !ceeg_aligned(out, 16) || (bias && !ceeg_aligned(bias, 16))) return CEEG_EINVAL;
   if (ex.bf16 && (accumulate || ex.addend || ex.xidx || (ex.nt & 1))) return CEEG_EUNSUPPORTED;
   if (nnz >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
   if (ws_bytes < ceeg_spmm_ws_bytes(N, nnz, F) || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
   unsigned int* queue = static_cast<unsigned int*>(ws);
   float* partial = reinterpret_cast<float*>(static_cast<char*>(ws) + SPMM_QUEUE_BYTES);
-  const int lpr = lpr_for(F);
+  const int epl = ex.bf16 ? 8 : 4;
+  if (ex.bf16 && ((F % 8) != 0 || (ldx % 8) != 0 || (ldo % 8) != 0 || (ex.mask && (ex.ld_mask % 8) != 0))) return CEEG_EUNSUPPORTED;  // 16-byte lanes
+  const int lpr = lpr_for(F, epl);
   int rc = CEEG_OK;
-  for (int fbase = 0; fbase < F && rc == CEEG_OK; fbase += 4 * lpr) {
+  for (int fbase = 0; fbase < F && rc == CEEG_OK; fbase += epl * lpr) {
 #define CEEG_SPMM_CASE(L)                                                                                                       \
   case L:                                                                                                                       \
     rc = ex.bf16 ? launch_pass<L, true>(rowptr, col, val, vperm, X, ldx, N, nnz, F, fbase, bias, relu, accumulate, out, ldo, partial, queue, st, ex) \
@@ -665,7 +715,7 @@ extern "C" int ceeg_spmm_csr_cv_bf16(const int32_t* rowptr, const void* colval, 
                                      const float* bias, int relu, const void* mask, int64_t ld_mask, void* out, int64_t ldo,
                                      int64_t max_row_nnz, const int32_t* long_items, int64_t n_long, void* ws, size_t ws_bytes, void* stream) {
   if (!colval && nnz > 0) return CEEG_EINVAL;
-  if (mask && (ld_mask < F || (ld_mask % 4) != 0 || !ceeg_aligned(mask, 8))) return CEEG_EINVAL;
+  if (mask && (ld_mask < F || (ld_mask % 8) != 0 || !ceeg_aligned(mask, 16))) return CEEG_EINVAL;
   if (n_long < 0 || (n_long > 0 && (!long_items || !ceeg_aligned(long_items, 16)))) return CEEG_EINVAL;
   if (max_row_nnz < 0 || (max_row_nnz > SPMM_CHUNK && n_long == 0)) return CEEG_EINVAL;
   static const int32_t no_items[4] = {0, 0, 0, 0};

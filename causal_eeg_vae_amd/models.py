@@ -1161,8 +1161,8 @@ class VariationalGCNEncoder(nn.Module):
             # opt-in reduced precision (north star: "rtol 1e-2 (bf16)"): activations stored as bf16 - every gathered row is half
             # the bytes -, dense products on the bf16 matrix cores, fp32 accumulation throughout; parameters, mu | logstd, the
             # noise, the quantiser and the decoder stay fp32.  Pass x already as bf16 to keep its conversion out of the step.
-            if not self.conv1.aggregate_first or D % 4 or x.shape[1] % 4:
-                raise ValueError("the bf16 encoder needs in_channels < 2 * latent and widths that are multiples of 4")
+            if not self.conv1.aggregate_first or D % 4 or x.shape[1] % 8:
+                raise ValueError("the bf16 encoder needs in_channels < 2 * latent, in_channels % 8 == 0 and latent % 4 == 0 (16-byte row pieces)")
             with torch.no_grad():
                 ax = graph.aggregate16(x if x.dtype == torch.bfloat16 else x.to(torch.bfloat16))
             ah = _LinearReluAggregate16.apply(ax, self.conv1.lin.weight, self.conv1.bias, graph)
