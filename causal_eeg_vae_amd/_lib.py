@@ -73,6 +73,7 @@ SIGNATURES = {
     "ceeg_bias_relu": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _c_int, _vp]),
     "ceeg_colsum_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_relu_bwd_colsum": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),
+    "ceeg_loss_sum": (_c_int, [_vp, _vp, _vp, _c_f32, _vp, _vp, _vp]),
     "ceeg_recon_finish": (_c_int, [_vp, _vp, _vp, _c_f32, _vp, _vp]),
     "ceeg_colsum": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),
     "ceeg_gat_softmax_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_f32, _vp, _vp]),

@@ -167,3 +167,25 @@ extern "C" int ceeg_recon_finish(const float* pos_sum, const float* neg_sum, con
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
+
+// loss = rec + kl * kl_scale + vq  (the loss sum of scripts/run.py:95 with the VGAE example's (1/N) kl_loss) in ONE launch; the
+// backward's three factors are (g, g * kl_scale, g): grads = { g, g * kl_scale } written by the same kernel when g is given.
+namespace {
+__global__ void loss_sum_kernel(const float* __restrict__ rec, const float* __restrict__ kl, const float* __restrict__ vq, float kl_scale,
+                                const float* __restrict__ g, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (g) {
+    out[0] = g[0];
+    out[1] = g[0] * kl_scale;
+  } else {
+    out[0] = rec[0] + kl[0] * kl_scale + vq[0];
+  }
+}
+}  // namespace
+
+extern "C" int ceeg_loss_sum(const float* rec, const float* kl, const float* vq, float kl_scale, const float* g, float* out, void* stream) {
+  if (!out || (!g && (!rec || !kl || !vq))) return CEEG_EINVAL;
+  hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), rec, kl, vq, kl_scale, g, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}

@@ -945,6 +945,33 @@ class _UniformRecon(torch.autograd.Function):
         return dz, None, None, None, None, None, None
 
 
+class _LossSum(torch.autograd.Function):
+    """loss = _loss_sum(rec, kl, vq_loss, N) (scripts/run.py:95 plus the VGAE example's (1/N) kl_loss) as one launch each way instead of
+    a chain of scalar torch kernels and their autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, rec, kl, vq_loss, kl_scale):
+        _lib.require_cuda(rec, kl, vq_loss)
+        out = torch.empty((), dtype=torch.float32, device=rec.device)
+        _lib.check(_lib.lib().ceeg_loss_sum(rec.data_ptr(), kl.data_ptr(), vq_loss.data_ptr(), float(kl_scale), None, out.data_ptr(), _lib.stream()),
+                   "ceeg_loss_sum")
+        ctx.kl_scale = float(kl_scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = torch.empty(2, dtype=torch.float32, device=g.device)
+        gc = g.contiguous()
+        _lib.check(_lib.lib().ceeg_loss_sum(None, None, None, ctx.kl_scale, gc.data_ptr(), gs.data_ptr(), _lib.stream()), "ceeg_loss_sum")
+        return gs[0], gs[1], gs[0], None
+
+
+def _loss_sum(rec, kl, vq_loss, n):
+    if rec.dtype == kl.dtype == vq_loss.dtype == torch.float32 and rec.dim() == kl.dim() == vq_loss.dim() == 0:
+        return _LossSum.apply(rec, kl, vq_loss, 1.0 / n)
+    return rec + kl / n + vq_loss
+
+
 class InnerProductDecoder(nn.Module):
     """PyG InnerProductDecoder: sigma(<z_i, z_j>) per edge (sigmoid=False: the raw inner product).  Inference-only: it
     carries no autograd path - training goes through VGAE.recon_loss, whose loss and gradient are fused kernels."""
@@ -1229,7 +1256,7 @@ class VGAEVQ(nn.Module):
         mu, logstd = encoder(x, graph);  z = reparametrize;  kl = kl_loss
         vq_loss, z_q, perplexity, _, idx = vector_quantization(z)      (scripts/models.py:32)
         rec = recon_loss(z_q) over the graph's edges and 1:1 permutation-structured negatives
-        loss = rec + kl / N + vq_loss                                   (loss sum as scripts/run.py:95)
+        loss = _loss_sum(rec, kl, vq_loss, N)                                   (loss sum as scripts/run.py:95)
     """
 
     def __init__(self, in_channels, latent, num_latent_embeddings=512, beta=0.25, seed=0, negatives="sigma", compute_dtype=torch.float32):
@@ -1260,7 +1287,7 @@ class VGAEVQ(nn.Module):
             if codes_on and graph.num_edges > 0 and N > 1 and _UniformRecon.supported(W, N, n_neg):
                 # both pair sets in code form, one dz; with no list given the pairs are drawn inside the forward kernel
                 rec, sums, neg_edge_index = _UniformRecon.apply(z_q, graph, neg_edge_index, W, code, self.negative_seed(step), n_neg)
-                loss = rec + kl / N + vq_loss
+                loss = _loss_sum(rec, kl, vq_loss, N)
                 return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums, neg_edge_index=neg_edge_index)
             if neg_edge_index is None:
                 neg_edge_index = negative_sampling_raw(graph, N, graph.num_edges, self.negative_seed(step))
@@ -1283,7 +1310,7 @@ class VGAEVQ(nn.Module):
             # z_q is bit-for-bit codebook[idx] in fp32: let the decoder gather 512 codebook rows through idx
             rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, None, self.vector_quantization.embedding.weight,
                                             idx.view(-1).to(torch.int32))
-        loss = rec + kl / N + vq_loss
+        loss = _loss_sum(rec, kl, vq_loss, N)
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums, neg_edge_index=neg_edge_index)
 
 
@@ -1342,7 +1369,7 @@ class ConditionalVGAEVQ(nn.Module):
                                             idx.view(-1).to(torch.int32), cn)
         else:
             rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
-        loss = rec + kl / N + vq_loss
+        loss = _loss_sum(rec, kl, vq_loss, N)
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)
 
 

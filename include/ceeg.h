@@ -399,6 +399,11 @@ int ceeg_colsum(const float* g, int64_t ldg, int64_t N, int F, float* colsum, vo
  *   out[3..5] = pos_sum, neg_sum, neg_count.   pos_sum / neg_sum / neg_count: one device float each; out: 6 device floats. */
 int ceeg_recon_finish(const float* pos_sum, const float* neg_sum, const float* neg_count, float pos_count, float* out, void* stream);
 
+/* The step's loss sum (scripts/run.py:95 `loss = recon_loss + embedding_loss`, plus the VGAE example's (1/N) kl_loss) in one
+ * launch: g == NULL: out[0] = rec + kl * kl_scale + vq;  g != NULL (backward): out[0] = g, out[1] = g * kl_scale.
+ * All operands are single device floats. */
+int ceeg_loss_sum(const float* rec, const float* kl, const float* vq, float kl_scale, const float* g, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * N1  GATConv attention (upstream PyG GATConv, instantiated by the reference at scripts/models.py:106), one head per
  * call.  rowptr/col: CSR grouped by destination with one self-loop per node (ceeg_csr_build self_loops=1 on the
