@@ -940,14 +940,28 @@ __global__ __launch_bounds__(256) void dc_sample_pair_fwd_kernel(const float* __
   }
 }
 
-// sorted keys -> row pointers: thread p closes every row between node[p-1] and node[p] (node fields >= N count as N)
+// sorted keys -> row pointers: position p closes every row between node[p-1] and node[p] (node fields >= N count as N); a thread
+// takes four consecutive positions from one 16-byte load (the keys array is the 256-byte aligned sort output)
 __global__ __launch_bounds__(256) void dc_pair_rowptr_kernel(const uint32_t* __restrict__ keys, int64_t M, int64_t N, int32_t* __restrict__ rowptr) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p > M) return;
-  int64_t cur = N, prev = -1;
-  if (p < M) { const int64_t k = (int64_t)(keys[p] >> DC_PAIR_NODE_SHIFT); cur = k < N ? k : N; }
-  if (p > 0) { const int64_t k = (int64_t)(keys[p - 1] >> DC_PAIR_NODE_SHIFT); prev = k < N ? k : N; }
-  for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)p;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (p0 > M) return;
+  auto node = [&](uint32_t k) -> int64_t { const int64_t n = (int64_t)(k >> DC_PAIR_NODE_SHIFT); return n < N ? n : N; };
+  uint32_t k[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  if (p0 + 4 <= M) {
+    const uint4 u = *reinterpret_cast<const uint4*>(keys + p0);
+    k[0] = u.x; k[1] = u.y; k[2] = u.z; k[3] = u.w;
+  } else {
+    for (int i = 0; i < 4; ++i) if (p0 + i < M) k[i] = keys[p0 + i];
+  }
+  int64_t prev = p0 > 0 ? node(keys[p0 - 1]) : -1;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t p = p0 + i;
+    if (p > M) break;
+    const int64_t cur = p < M ? node(k[i]) : N;
+    for (int64_t r = prev + 1; r <= cur; ++r) rowptr[r] = (int32_t)p;
+    prev = cur;
+  }
 }
 
 struct DcPairGradArgs {
@@ -1136,7 +1150,7 @@ extern "C" int ceeg_pair_bce_codes_bwd(const float* W, int64_t ldw, int n_e, int
     if (rocprim::radix_sort_keys(w.temp, tb, keys, w.keys_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
                                  (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
       return CEEG_ELAUNCH;
-    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
+    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M / 4 + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
     CEEG_CHECK_LAUNCH();
   } else if (hipMemsetAsync(w.rowptr, 0, ((size_t)N + 1) * 4, st) != hipSuccess) {  // the empty list: every row is empty
     return CEEG_ELAUNCH;
@@ -1221,7 +1235,7 @@ extern "C" int ceeg_decoder_codes_bwd_pairs(const float* W, int64_t ldw, int n_e
     if (rocprim::radix_sort_keys(w.temp, tb, keys, w.keys_out, (size_t)M, (unsigned)DC_PAIR_NODE_SHIFT,
                                  (unsigned)DC_PAIR_NODE_SHIFT + dc_key_bits(N), st, false) != hipSuccess)
       return CEEG_ELAUNCH;
-    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
+    hipLaunchKernelGGL(dc_pair_rowptr_kernel, dim3((unsigned)((M / 4 + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, M, N, w.rowptr);
     CEEG_CHECK_LAUNCH();
   } else if (hipMemsetAsync(w.rowptr, 0, ((size_t)N + 1) * 4, st) != hipSuccess) {
     return CEEG_ELAUNCH;
