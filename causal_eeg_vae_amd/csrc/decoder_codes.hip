@@ -119,11 +119,18 @@ __global__ __launch_bounds__(256) void dc_gram_kernel(const float* __restrict__ 
   G[(size_t)a * K + b] = acc;
 }
 
+// codes as clamped 16-bit values: the array the pair kernels read at random shrinks to 2 bytes per node (2 MB at N = 1 M) and
+// stays in L2 next to the 1 MB term table while the pair / key streams and the sampler's bitmap lines flow past
+__global__ __launch_bounds__(256) void dc_code16_kernel(const int32_t* __restrict__ code, int64_t N, int K, unsigned short* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < N) out[i] = (unsigned short)dc_clamp_code(code[i], K);
+}
+
 // ------------------------------------------------------------------------------------------------ forward: coefficients
 // Wave w owns rows [64 w, 64 w + 64): the row pointers, sigma-rows and codes of all 64 arrive in one lane-parallel
 // load; group g walks rows 4 it + g, 16 entries at a time.  Static assignment: the loss partial of wave w goes to slot w,
 // so the sums do not depend on scheduling.
-__global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const unsigned short* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
                                                            int64_t sig_a, int64_t sig_b, int64_t sig_mod, const float* __restrict__ row_add,
                                                            uint4* __restrict__ rec, float* __restrict__ part, int no_neg) {
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
     sr = (int)ceeg_block_affine(r, sig_a, sig_b, sig_mod);
     slo = rowptr[sr];
     shi = rowptr[sr + 1];
-    kr = dc_clamp_code(code[r], K);
-    ksr = dc_clamp_code(code[sr], K);
+    kr = code[r];
+    ksr = code[sr];
     if (hi - lo > DC_CHUNK) hi = lo;  // hub row: dc_coef_long_kernel
   }
   const int cnt = N - row0 < 64 ? (int)(N - row0) : 64;
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
       int c = 0, kc = 0;
       if (live) {
         c = col[p];
-        kc = dc_clamp_code(code[c], K);
+        kc = code[c];
       }
       bool hit = false;
 #define DC_HIT(T) hit |= (c == dc_bcast<T>(sc));
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
 }
 
 // pieces of hub rows: one wave per item (lo, hi, chunk*2+slot, row), 64 entries at a time; loss partial -> slot0 + item
-__global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restrict__ G, int K, const int32_t* __restrict__ code,
+__global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restrict__ G, int K, const unsigned short* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                            const int4* __restrict__ items, int64_t n_items, int64_t sig_a, int64_t sig_b,
                                                            int64_t sig_mod, const float* __restrict__ row_add, uint4* __restrict__ rec,
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
   const int lo = itv.x, hi = itv.y, r = itv.w;
   const int sr = (int)ceeg_block_affine((int64_t)r, sig_a, sig_b, sig_mod);
   const int slo = rowptr[sr], shi = rowptr[sr + 1];
-  const int kr = dc_clamp_code(code[r], K), ksr = dc_clamp_code(code[sr], K);
+  const int kr = code[r], ksr = code[sr];
   const float* gr = G + (size_t)kr * K;
   const float* gs = G + (size_t)ksr * K;
   const float radd = row_add ? row_add[r] : 0.f;
@@ -213,7 +220,7 @@ __global__ __launch_bounds__(256) void dc_coef_long_kernel(const float* __restri
     const int p = base + lane;
     if (p < hi) {
       const int c = col[p];
-      const int kc = dc_clamp_code(code[c], K);
+      const int kc = code[c];
       float tp, cp, tn, cn;
       dc_terms(gr[kc] + radd, gs[kc] + radd, tp, cp, tn, cn);
       const bool valid = !no_neg && c != sr && !dc_sorted_has(col, slo, shi, c);
@@ -586,7 +593,7 @@ extern "C" int ceeg_decoder_codes_supported(int n_e, int D) { return dc_supporte
 
 extern "C" size_t ceeg_decoder_codes_ws_bytes(int64_t N, int64_t nnz, int n_e, int D, int64_t n_long, int64_t n_tlong) {
   if (N <= 0 || nnz < 0 || !dc_supported(n_e, D) || n_long < 0 || n_tlong < 0) return 0;
-  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part(((size_t)((N + 63) / 64) + (size_t)n_long) * 3, 4);
+  const size_t fwd = ceeg_ws_part((size_t)n_e * n_e, 4) + ceeg_ws_part(((size_t)((N + 63) / 64) + (size_t)n_long) * 3, 4) + ceeg_ws_part((size_t)N, 2);
   const size_t bwd = 1024 + dc_part_bytes(nnz, D, n_long) + dc_part_bytes(nnz, D, n_tlong) + dc_cpart_bytes(nnz, n_long) + dc_cpart_bytes(nnz, n_tlong);
   return fwd > bwd ? fwd : bwd;
 }
@@ -609,14 +616,17 @@ extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int 
   float* part = reinterpret_cast<float*>(static_cast<char*>(ws) + ceeg_ws_part((size_t)n_e * n_e, 4));
   const int64_t nwave = (N + 63) / 64;
   const int64_t nslot = nwave + n_long;
+  unsigned short* code16 = reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(part) + ceeg_ws_part((size_t)nslot * 3, 4));
+  hipLaunchKernelGGL(dc_code16_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, code, N, n_e, code16);  // 2 bytes per node: L2-resident
+  CEEG_CHECK_LAUNCH();
   hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
   CEEG_CHECK_LAUNCH();
   uint4* r4 = static_cast<uint4*>(rec);
-  hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col, N, sig_a, sig_b,
+  hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col, N, sig_a, sig_b,
                      sig_mod, row_add, r4, part, no_neg);
   CEEG_CHECK_LAUNCH();
   if (n_long > 0) {
-    hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code, rowptr, col,
+    hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col,
                        reinterpret_cast<const int4*>(long_items), n_long, sig_a, sig_b, sig_mod, row_add, r4, part, nwave, no_neg);
     CEEG_CHECK_LAUNCH();
   }
@@ -833,13 +843,6 @@ __global__ __launch_bounds__(256) void dc_pair_tables_kernel(const float* __rest
   dc_terms(v, v, tp, cp, tn, cn);
   T[i] = negative ? tn : tp;
   C[i] = negative ? cn : cp;
-}
-
-// codes as clamped 16-bit values: the array the pair kernels read at random shrinks to 2 bytes per node (2 MB at N = 1 M) and
-// stays in L2 next to the 1 MB term table while the pair / key streams and the sampler's bitmap lines flow past
-__global__ __launch_bounds__(256) void dc_code16_kernel(const int32_t* __restrict__ code, int64_t N, int K, unsigned short* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < N) out[i] = (unsigned short)dc_clamp_code(code[i], K);
 }
 
 __global__ __launch_bounds__(256) void dc_pair_fwd_kernel(const float* __restrict__ T, int K, const unsigned short* __restrict__ code,
