@@ -101,9 +101,21 @@ __device__ __forceinline__ void sp_store_f32(float* __restrict__ p, const SpAcc<
 }
 __device__ __forceinline__ unsigned sp_pack2(float lo, float hi) { return (unsigned)ceeg_f32_to_bf16(lo) | ((unsigned)ceeg_f32_to_bf16(hi) << 16); }
 
+// The finished 16 bytes of the previous row, stored only after the next row's first gathers are in flight: on gfx9 stores and
+// loads share vmcnt and retire in order, so a store issued BEFORE those gathers sits in front of them in every wait
+// (F = 256 aggregation of config 2: 1.42 -> 1.38 ms; profiles/r03_spmm_bound.txt).
+struct SpPend {
+  uint4 raw;
+  void* addr = nullptr;  // per lane; nullptr = nothing pending
+  __device__ __forceinline__ void flush() {
+    if (addr) *reinterpret_cast<uint4*>(addr) = raw;
+    addr = nullptr;
+  }
+};
+
 template <int LPR, int K, bool BF = false>
 __device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n, int sub, const void* __restrict__ X,
-                                             int64_t ldx, int foff, bool fl_ok, SpAcc<BF>& acc) {
+                                             int64_t ldx, int foff, bool fl_ok, SpAcc<BF>& acc, SpPend* pend = nullptr) {
   constexpr int G = 64 / LPR;
   uint4 x[K];
   float v[K];
@@ -124,6 +136,7 @@ __device__ __forceinline__ void gather_steps(int my_c, float my_v, int i0, int n
     x[k] = make_uint4(0u, 0u, 0u, 0u);
     if (ld) x[k] = sp_load_raw<BF>(X, (int64_t)c * ldx + foff);
   }
+  if (pend) pend->flush();
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     if constexpr (G > 1) {
@@ -161,7 +174,7 @@ template <int LPR, bool BF = false>
 __device__ __forceinline__ SpAcc<BF> seg_sum_pre(const int32_t* __restrict__ col, const float* __restrict__ val,
                                               const int32_t* __restrict__ vperm, const void* __restrict__ X, int64_t ldx,
                                               int p_lo, int p_hi, int lane, int foff, bool fl_ok, const CeegSpmmEx& ex,
-                                              int my_c, float my_v) {
+                                              int my_c, float my_v, SpPend* pend = nullptr) {
   constexpr int G = 64 / LPR;
   const int sub = lane / LPR;
   SpAcc<BF> acc = sp_zero<BF>();
@@ -170,11 +183,11 @@ __device__ __forceinline__ SpAcc<BF> seg_sum_pre(const int32_t* __restrict__ col
     if (base != p_lo) load_batch(col, val, vperm, base, p_hi, lane, ex, my_c, my_v);
     const int ns = (n + G - 1) / G;  // steps in this batch (wave-uniform)
     int i0 = 0;
-    for (; i0 + 8 <= ns; i0 += 8) gather_steps<LPR, 8, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc);
+    for (; i0 + 8 <= ns; i0 += 8) gather_steps<LPR, 8, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc, pend);
     const int rem = ns - i0;
-    if (rem & 4) { gather_steps<LPR, 4, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 4; }
-    if (rem & 2) { gather_steps<LPR, 2, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); i0 += 2; }
-    if (rem & 1) { gather_steps<LPR, 1, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc); }
+    if (rem & 4) { gather_steps<LPR, 4, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc, pend); i0 += 4; }
+    if (rem & 2) { gather_steps<LPR, 2, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc, pend); i0 += 2; }
+    if (rem & 1) { gather_steps<LPR, 1, BF>(my_c, my_v, i0, n, sub, X, ldx, foff, fl_ok, acc, pend); }
   }
   if constexpr (G > 1) {
 #pragma unroll
@@ -323,6 +336,7 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
   if (p_hi - p_lo <= SPMM_CHUNK) load_batch(col, val, vperm, p_lo, p_hi, lane, ex, bc, bv);
   int rp_n = row_ptrs(base_nxt);
   unsigned int draw = 0;
+  SpPend pend;
   for (int it = 0; base_cur < r_end; ++it) {
     if (threadIdx.x == 0) draw = atomicAdd(q, (unsigned)SPMM_GRAB);  // draw it+2
     // (col,val) batch of the next row
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
       uint4 mk_raw = make_uint4(0u, 0u, 0u, 0u);
       if (ex.mask && lane < LPR && fl_ok) mk_raw = sp_load_raw<BF>(ex.mask, r * ex.ld_mask + foff);  // in flight under the gathers
       if (p_hi - p_lo <= SPMM_CHUNK) {
-        acc = seg_sum_pre<LPR, BF>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv);
+        acc = seg_sum_pre<LPR, BF>(col, val, vperm, X, ldx, p_lo, p_hi, lane, foff, fl_ok, ex, bc, bv, &pend);
       } else {
         acc = sp_zero<BF>();
         const int c_lo = p_lo / SPMM_CHUNK, c_hi = (p_hi - 1) / SPMM_CHUNK;
@@ -377,14 +391,18 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
         }
         if constexpr (BF) {  // rounded to nearest-even once, on the store
           const uint4 u = make_uint4(sp_pack2(acc.a.x, acc.a.y), sp_pack2(acc.a.z, acc.a.w), sp_pack2(acc.b.x, acc.b.y), sp_pack2(acc.b.z, acc.b.w));
-          *reinterpret_cast<uint4*>(static_cast<unsigned short*>(out) + ro * ldo + foff) = u;
+          pend.flush();
+          pend.raw = u;
+          pend.addr = static_cast<unsigned short*>(out) + ro * ldo + foff;
         } else {
           float* o = static_cast<float*>(out) + ro * ldo + foff;
           if (ex.nt & 1) {  // once-written output rows: keep them from evicting gathered rows
             __builtin_nontemporal_store(acc.a.x, o); __builtin_nontemporal_store(acc.a.y, o + 1);
             __builtin_nontemporal_store(acc.a.z, o + 2); __builtin_nontemporal_store(acc.a.w, o + 3);
           } else {
-            *reinterpret_cast<float4*>(o) = acc.a;
+            pend.flush();  // a row without gathers in between (empty, or summed from pieces)
+            pend.raw = make_uint4(__float_as_uint(acc.a.x), __float_as_uint(acc.a.y), __float_as_uint(acc.a.z), __float_as_uint(acc.a.w));
+            pend.addr = o;
           }
         }
       }
@@ -398,7 +416,9 @@ __global__ __launch_bounds__(SPMM_WAVES * 64) void spmm_rows_kernel(
     p_lo = p_lo_n; p_hi = p_hi_n; bc = bc_n; bv = bv_n;
     rp_n = row_ptrs(base_nn);
   }
+  pend.flush();
 }
+
 
 int lpr_for(int F, int epl = 4) {
   const int need = (F + epl - 1) / epl;

@@ -12,6 +12,7 @@ from causal_eeg_vae_amd.synth import synth_event_graph  # noqa: E402
 
 N, E = 1_000_000, 16_000_000
 dev = torch.device("cuda")
+torch.manual_seed(0)
 L = _lib.lib()
 g = EventGraph(synth_event_graph(N, E, seed=1000, device=dev), N)
 p = g.gcn
@@ -52,4 +53,5 @@ for F in (256, 128):
                                           _lib.stream()), "cv")
 
         ta, tb = timeit(a), timeit(b)
-        print(f"F={F} {name}: separate streams {ta:.3f} ms, interleaved {tb:.3f} ms, equal {torch.equal(out_a, out_b)}")
+        chk = int(out_b.view(torch.int32).to(torch.int64).sum().item()) & 0xffffffffffff  # compares runs with different CEEG_SPMM_* switches
+        print(f"F={F} {name}: separate streams {ta:.3f} ms, interleaved {tb:.3f} ms, equal {torch.equal(out_a, out_b)}, bits {chk:012x}")
