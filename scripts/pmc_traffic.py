@@ -26,10 +26,10 @@ for neg in ("uniform", "sigma"):
         fr, wr = f[k]["sum"] * KIB / 1e9, w.get(k, {"sum": 0.0})["sum"] * KIB / 1e9
         b = 2 * fr + wr
         tot += b
-        if k.startswith("spmm_rows_kernel<64>"):
+        if k.startswith("spmm_rows_kernel<64"):
             spmm += b
             n_spmm += f[k]["launches"]
-        if k.startswith("spmm_long_items_kernel<64>"):
+        if k.startswith("spmm_long_items_kernel<64"):
             spmm += b
         if any(t in k for t in DEC) and "csr_" not in k:
             dec += b
