@@ -35,6 +35,8 @@ SIGNATURES = {
     "ceeg_gcn_norm": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp]),
     "ceeg_csr_long_items_ws_bytes": (_c_sz, [_c_i64]),
     "ceeg_csr_long_items": (_c_int, [_vp, _c_i64, _c_int, _vp, _c_i64, _vp, _vp, _c_sz, _vp]),
+    "ceeg_csr_add_self_loops_ws_bytes": (_c_sz, [_c_i64]),
+    "ceeg_csr_add_self_loops": (_c_int, [_vp] * 6 + [_c_i64] + [_vp] * 6 + [_vp, _c_sz, _vp]),
     "ceeg_spmm_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
     "ceeg_spmm_csr": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_sz, _vp]),
     "ceeg_spmm_csr_items": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_int, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_sz, _vp]),

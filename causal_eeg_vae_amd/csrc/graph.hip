@@ -392,6 +392,114 @@ extern "C" int ceeg_csr_long_items(const int32_t* rowptr, int64_t N, int chunk, 
   return CEEG_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- A + I from the raw-edge pair
+// A minibatch loop builds BOTH structures of a graph every step - the raw edges for the decoder, A + I for the encoder (PyG
+// add_remaining_self_loops: input self-loops dropped, one loop per node that keeps the last input loop's edge id) - and the
+// second one does not need a second sort: row r of A + I is row r of the raw CSR with its run of `col == r` entries (contiguous:
+// rows are sorted by column, equal pairs by edge id) replaced by ONE loop entry at the same place.  The same holds for the
+// transposed rows, and both orientations drop the same number of entries per row, so one prefix sum serves both.
+namespace {
+// thread per row: lt[r] = entries with col < r, loops[r] = entries with col == r
+__global__ __launch_bounds__(256) void csr_loops_count_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
+                                                              int32_t* __restrict__ lt, int32_t* __restrict__ loops) {
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r > N) return;
+  if (r == N) {
+    if (loops) loops[N] = 0;
+    return;
+  }
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  int a = lo, b = hi;
+  while (a < b) {  // first position with col >= r
+    const int m = (a + b) >> 1;
+    if (col[m] < (int32_t)r) a = m + 1; else b = m;
+  }
+  int e = a;
+  while (e < hi && col[e] == (int32_t)r) ++e;
+  lt[r] = a - lo;
+  if (loops) loops[r] = e - a;
+}
+
+// 16 lanes per row.  TRANSPOSED = false: (col, perm) are the raw CSR's columns and edge ids, the loop entry gets the last dropped
+// loop's edge id or -1.  TRANSPOSED = true: (col, perm) are the raw transpose's (t_col, t_perm); an entry's t_perm becomes its
+// position in the NEW forward CSR (f_* = the raw forward row pointers, g_rowptr = the new ones, f_lt = loop position inside a
+// forward row), the loop entry of row r points at the forward loop entry of row r.
+template <bool TRANSPOSED>
+__global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ perm, const int32_t* __restrict__ lt,
+                                                             const int32_t* __restrict__ loops_scan /* exclusive, N + 1 */, int64_t N,
+                                                             const int32_t* __restrict__ f_rowptr, const int32_t* __restrict__ f_lt,
+                                                             const int32_t* __restrict__ g_rowptr, int32_t* __restrict__ o_rowptr,
+                                                             int32_t* __restrict__ o_col, int32_t* __restrict__ o_perm) {
+  const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (r >= N) return;
+  const int l = threadIdx.x & 15;
+  const int lo = rowptr[r], hi = rowptr[r + 1];
+  const int s0 = loops_scan[r], nl = loops_scan[r + 1] - s0, a = lt[r];
+  const int base = lo - s0 + (int)r;
+  if (l == 0) {
+    o_rowptr[r] = base;
+    if (r == N - 1) o_rowptr[N] = hi - loops_scan[N] + (int)N;
+    o_col[base + a] = (int32_t)r;
+    if constexpr (TRANSPOSED) o_perm[base + a] = g_rowptr[r] + f_lt[r];
+    else o_perm[base + a] = nl > 0 ? perm[lo + a + nl - 1] : -1;
+  }
+  for (int p = lo + l; p < hi; p += 16) {
+    const int k = p - lo;
+    if (k >= a && k < a + nl) continue;  // an input self-loop
+    const int q = base + (k < a ? k : k - nl + 1);
+    const int32_t c = col[p];
+    o_col[q] = c;
+    if constexpr (TRANSPOSED) {
+      const int fp = perm[p];                       // position in the raw forward CSR, in forward row c, whose column is r
+      const int fnl = loops_scan[c + 1] - loops_scan[c];
+      o_perm[q] = g_rowptr[c] + (fp - f_rowptr[c]) + ((int32_t)r > c ? 1 - fnl : 0);
+    } else {
+      o_perm[q] = perm[p];
+    }
+  }
+}
+}  // namespace
+
+extern "C" size_t ceeg_csr_add_self_loops_ws_bytes(int64_t N) {
+  if (N <= 0) return 0;
+  return 4 * ceeg_ws_part((size_t)N + 1, 4) + ceeg_align_up(piece_scan_temp(N + 1), 256);
+}
+
+extern "C" int ceeg_csr_add_self_loops(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* t_rowptr,
+                                       const int32_t* t_col, const int32_t* t_perm, int64_t N, int32_t* g_rowptr, int32_t* g_col,
+                                       int32_t* g_perm, int32_t* gt_rowptr, int32_t* gt_col, int32_t* gt_perm, void* ws, size_t ws_bytes,
+                                       void* stream) {
+  if (N <= 0 || !rowptr || !col || !perm || !t_rowptr || !t_col || !t_perm || !g_rowptr || !g_col || !g_perm || !gt_rowptr || !gt_col ||
+      !gt_perm)
+    return CEEG_EINVAL;
+  if (N >= ((int64_t)1 << 31) - 1) return CEEG_EUNSUPPORTED;
+  const size_t need = ceeg_csr_add_self_loops_ws_bytes(N);
+  if (need == 0 || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CeegWs a(ws, ws_bytes);
+  int32_t* lt = a.take<int32_t>((size_t)N + 1);
+  int32_t* t_lt = a.take<int32_t>((size_t)N + 1);
+  int32_t* loops = a.take<int32_t>((size_t)N + 1);
+  int32_t* scan = a.take<int32_t>((size_t)N + 1);
+  size_t tb = piece_scan_temp(N + 1);
+  void* temp = a.take<char>(tb);
+  if (!a.ok) return CEEG_EWORKSPACE;
+  const dim3 rows((unsigned)((N + 1 + 255) / 256)), groups((unsigned)((N + 15) / 16));
+  hipLaunchKernelGGL(csr_loops_count_kernel, rows, dim3(256), 0, st, rowptr, col, N, lt, loops);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(csr_loops_count_kernel, rows, dim3(256), 0, st, t_rowptr, t_col, N, t_lt, static_cast<int32_t*>(nullptr));
+  CEEG_CHECK_LAUNCH();
+  if (rocprim::exclusive_scan(temp, tb, loops, scan, 0, (size_t)N + 1, rocprim::plus<int32_t>(), st, false) != hipSuccess) return CEEG_ELAUNCH;
+  hipLaunchKernelGGL(csr_loops_fill_kernel<false>, groups, dim3(256), 0, st, rowptr, col, perm, lt, scan, N, static_cast<const int32_t*>(nullptr),
+                     static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), g_rowptr, g_col, g_perm);
+  CEEG_CHECK_LAUNCH();
+  hipLaunchKernelGGL(csr_loops_fill_kernel<true>, groups, dim3(256), 0, st, t_rowptr, t_col, t_perm, t_lt, scan, N, rowptr, lt, g_rowptr, gt_rowptr,
+                     gt_col, gt_perm);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
 extern "C" int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew,
                              int64_t nnz, int64_t N, float* deg_inv_sqrt, float* val, void* stream) {
   if (N <= 0 || nnz < 0 || !rowptr || !deg_inv_sqrt || (nnz > 0 && (!col || !val)) || (ew && !perm)) return CEEG_EINVAL;

@@ -35,33 +35,44 @@ class CsrPair:
     counts) arrives in ONE small device record read once by `finalize()`.  `defer=True` leaves that read to the caller, so that
     several structures (EventGraph's two pairs, a collation's layout check) share a single host synchronisation."""
 
-    def __init__(self, edge_index, num_nodes, self_loops, defer=False):
+    def __init__(self, edge_index, num_nodes, self_loops, defer=False, raw=None):
         _lib.require_cuda(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
         L = _lib.lib()
         dev = edge_index.device
-        ei = edge_index.to(torch.int64).contiguous()
-        E, N = ei.shape[1], int(num_nodes)
+        E, N = edge_index.shape[1], int(num_nodes)
         cap = max(E + (N if self_loops else 0), 1)
         self.num_nodes, self.self_loops = N, bool(self_loops)
         self._cap = cap
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(cap, dtype=torch.int32, device=dev)
         self.perm = torch.empty(cap, dtype=torch.int32, device=dev)
-        ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
-        _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
-                                    self.col.data_ptr(), self.perm.data_ptr(), None, ws.data_ptr(), ws.numel(),
-                                    _lib.stream()), "ceeg_csr_build")
-        # the transpose runs on the CAPACITY: the true entry count (input self-loops dropped, out-of-range ids skipped) stays
-        # on the device until finalize()
         self.t_rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.t_col = torch.empty(cap, dtype=torch.int32, device=dev)
         self.t_perm = torch.empty(cap, dtype=torch.int32, device=dev)
-        ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(cap, N), dev)
-        _lib.check(L.ceeg_csr_transpose(self.rowptr.data_ptr(), self.col.data_ptr(), cap, N, self.t_rowptr.data_ptr(),
-                                        self.t_col.data_ptr(), self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(),
-                                        _lib.stream()), "ceeg_csr_transpose")
+        if raw is not None:
+            # `raw` = the not yet finalised raw-edge pair of the SAME edge list: A + I is that structure with every row's run of
+            # self-loops replaced by one loop entry (ceeg_csr_add_self_loops) - no second sort, no second transpose
+            if not self_loops or raw.self_loops or raw.num_nodes != N or raw._items is None or raw._cap != max(E, 1):
+                raise ValueError("raw must be the unfinalised raw-edge CsrPair (self_loops=False) of the same edge list")
+            ws = _lib.workspace(L.ceeg_csr_add_self_loops_ws_bytes(N), dev)
+            _lib.check(L.ceeg_csr_add_self_loops(raw.rowptr.data_ptr(), raw.col.data_ptr(), raw.perm.data_ptr(), raw.t_rowptr.data_ptr(),
+                                                 raw.t_col.data_ptr(), raw.t_perm.data_ptr(), N, self.rowptr.data_ptr(), self.col.data_ptr(),
+                                                 self.perm.data_ptr(), self.t_rowptr.data_ptr(), self.t_col.data_ptr(),
+                                                 self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_csr_add_self_loops")
+        else:
+            ei = edge_index.to(torch.int64).contiguous()
+            ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
+            _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
+                                        self.col.data_ptr(), self.perm.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                        _lib.stream()), "ceeg_csr_build")
+            # the transpose runs on the CAPACITY: the true entry count (input self-loops dropped, out-of-range ids skipped) stays
+            # on the device until finalize()
+            ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(cap, N), dev)
+            _lib.check(L.ceeg_csr_transpose(self.rowptr.data_ptr(), self.col.data_ptr(), cap, N, self.t_rowptr.data_ptr(),
+                                            self.t_col.data_ptr(), self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _lib.stream()), "ceeg_csr_transpose")
         # row statistics + piece lists of both orientations -> one record [nnz, max_row, n_long, nnz, max_trow, n_tlong]
         chunk = int(L.ceeg_decoder_codes_chunk())
         icap = 3 * cap // chunk + 4
@@ -137,8 +148,9 @@ class EventGraph:
         self.edge_index = edge_index
         self.num_nodes = int(num_nodes)
         self.num_edges = int(edge_index.shape[1])
-        self.gcn = CsrPair(edge_index, num_nodes, self_loops=True, defer=True)
         self._dec = CsrPair(edge_index, num_nodes, self_loops=False, defer=True) if with_dec else None
+        derive = with_dec and os.environ.get("CEEG_GCN_FROM_RAW", "1") == "1"
+        self.gcn = CsrPair(edge_index, num_nodes, self_loops=True, defer=True, raw=self._dec if derive else None)
         names = list(checks or {})
         parts = [self.gcn._rec] + ([self._dec._rec] if with_dec else [])
         if names:

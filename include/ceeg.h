@@ -145,6 +145,17 @@ int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm
 size_t ceeg_csr_long_items_ws_bytes(int64_t N);
 int ceeg_csr_long_items(const int32_t* rowptr, int64_t N, int chunk, int32_t* items, int64_t items_cap, int64_t* record,
                         void* ws, size_t ws_bytes, void* stream);
+/* add_remaining_self_loops on a structure that is already sorted: from the raw-edge pair (ceeg_csr_build with self_loops = 0 and
+ * its ceeg_csr_transpose) to the pair of A + I, entry for entry what ceeg_csr_build(self_loops = 1) + ceeg_csr_transpose give
+ * (every input self-loop dropped, one (i,i) entry per node at its sorted place, g_perm = edge ids with the last dropped loop's id
+ * or -1 on the loop entries, gt_perm = positions in the new forward structure) - without a second sort.  For loops that build both
+ * structures of a new minibatch every step (scripts/run.py:310-326: the encoder's gcn_norm graph and the decoder's edge list).
+ * Output capacity: rowptr[N] + N entries each.  All arrays int32 on the device. */
+size_t ceeg_csr_add_self_loops_ws_bytes(int64_t N);
+int ceeg_csr_add_self_loops(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* t_rowptr,
+                            const int32_t* t_col, const int32_t* t_perm, int64_t N, int32_t* g_rowptr, int32_t* g_col,
+                            int32_t* g_perm, int32_t* gt_rowptr, int32_t* gt_col, int32_t* gt_perm, void* ws, size_t ws_bytes,
+                            void* stream);
 
 /* Deterministic CSR segmented SpMM (the GCNConv aggregation and every transposed/backward pass):
  *   out[i,:] = act( sum_{p=rowptr[i]}^{rowptr[i+1]-1} v(p) * X[col[p],:]  + bias )      i in [0,N)

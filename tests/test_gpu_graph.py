@@ -57,15 +57,25 @@ def test_csr_build_transpose_bit_exact(N, E, self_loops, hubs):
             assert torch.equal(items, build_long_items(torch.from_numpy(rp.astype(np.int32)).cuda(), chunk))
 
 
-def test_event_graph_single_read_construction():
+@pytest.mark.parametrize("from_raw", ["1", "0"])
+@pytest.mark.parametrize("N,E", [(3000, 50000), (1, 3), (2, 5), (70, 40)])
+def test_event_graph_single_read_construction(N, E, from_raw, monkeypatch):
     """EventGraph(with_dec=True, checks=...) builds both pairs and reads every host-side quantity in one record; ids outside
     [0, N) and input self-loops make the entry counts data-dependent (nnz < capacity) and the structures still equal the
-    oracle's."""
+    oracle's.  from_raw = 1: A + I derived from the raw-edge pair (ceeg_csr_add_self_loops), 0: built by its own sort - the input
+    has repeated self-loops on one node, repeated edges, nodes without any edge and (N = 1) nothing but loops."""
     from causal_eeg_vae_amd import EventGraph
     from oracle import ref_torch
-    N, E = 3000, 50000
-    src, dst = _rand_graph(N, E, 5, hubs=600)
-    src[:5] = -1; dst[5:9] = N + 3                        # skipped by the builder
+    monkeypatch.setenv("CEEG_GCN_FROM_RAW", from_raw)
+    src, dst = _rand_graph(N, E, 5, hubs=max(N // 5, 1))
+    if N >= 70:
+        src[:5] = -1; dst[5:9] = N + 3                    # skipped by the builder
+        src[9:12] = dst[9:12] = 17                        # three loops on one node: the last one's edge id survives
+        src[12:14] = dst[12:14] = N - 1
+        src[14:17] = 3; dst[14:17] = 40                   # a repeated edge
+        keep = (src != 33) & (dst != 33)                  # node 33: no edge at all
+        src, dst = np.where(keep, src, 1), np.where(keep, dst, 2)
+        E = src.shape[0]
     ei = torch.from_numpy(np.stack([src, dst])).cuda()
     g = EventGraph(ei, N, with_dec=True, checks={"yes": torch.ones((), dtype=torch.bool, device="cuda"), "no": (ei[0] > N + 5).any()})
     assert g.checks == {"yes": True, "no": False} and g._dec is not None
@@ -73,7 +83,7 @@ def test_event_graph_single_read_construction():
     eid = np.nonzero(ok)[0]
     for pair, loops in ((g.gcn, True), (g.dec, False)):
         rowptr, col, perm = ref_torch.csr_build_np(src[ok], dst[ok], N, loops)
-        assert pair.nnz == rowptr[-1] < E + (N if loops else 0)
+        assert pair.nnz == rowptr[-1] <= E + (N if loops else 0) and (N < 70 or pair.nnz < E + (N if loops else 0))
         np.testing.assert_array_equal(pair.rowptr.cpu().numpy(), rowptr)
         np.testing.assert_array_equal(pair.col.cpu().numpy(), col)
         np.testing.assert_array_equal(pair.perm.cpu().numpy(), np.where(perm >= 0, eid[np.maximum(perm, 0)], -1))
