@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--fresh-batches", type=int, default=0,
                     help="cvgae only: K > 0 = a minibatch stream - K resident minibatches visited round-robin, collation and graph construction "
                          "inside the timed region of every step (scripts/run.py:310-326)")
+    ap.add_argument("--prefetch", action="store_true",
+                    help="with --fresh-batches: build minibatch k+1 on a side stream while step k runs (collate.MinibatchStream)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="cvgae only (SURVEY.md 8(d) config 4): weak = --graphs per rank; strong = the --graphs minibatch split over the ranks")
     return ap.parse_args()
@@ -185,7 +187,7 @@ def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
                                     f"latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 permutation-structured negatives, Adam")
 
 
-def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=None):
+def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=None, prefetch=False):
     """configs[3] as the minibatch STREAM the reference's loader produces (scripts/run.py:310-326: a new batch every step):
     `fresh` pre-generated minibatches (per-graph edge lists, features and conditions resident in HBM) are visited round-robin and
     EVERYTHING per-batch happens inside the timed region - device collation (CollatedBatch), both CSR pairs with their
@@ -208,32 +210,30 @@ def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=N
     trainer = Trainer(model, lr=1e-3, world_size=world)
     sync = barrier or torch.cuda.synchronize
     sizes = [n] * G
-    evs = []
+    from causal_eeg_vae_amd.collate import MinibatchStream
 
-    def one(k, timed):
-        eis, x, cond = batches[k % fresh]
-        if timed:
-            s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-        cb = CollatedBatch(eis, sizes)
-        graph = cb.event_graph(with_dec=True)
-        if timed:
-            t.record()
-            evs.append((s, t))
-        return trainer.step(x, graph, cb.batch, cond, nodes_per_graph=n)
+    def loop(k0, count, timing):
+        # the loader loop: collation + graph construction of every minibatch inside the loop (prefetch: minibatch k+1 is built
+        # on a side stream while step k runs; the construction is still part of the timed region, only overlapped)
+        ms = MinibatchStream(((batches[k % fresh][0], sizes) for k in range(k0, k0 + count)), with_dec=True, prefetch=prefetch, timing=timing)
+        loss = None
+        for k, (cb, graph) in zip(range(k0, k0 + count), ms):
+            _, x, cond = batches[k % fresh]
+            loss, _ = trainer.step(x, graph, cb.batch, cond, nodes_per_graph=n)
+        return loss, ms.build_events
 
-    for k in range(warmup):
-        one(k, False)
+    loop(0, warmup, False)
     sync()
     t0 = time.perf_counter()
-    for k in range(steps):
-        loss, aux = one(warmup + k, True)
+    loss, evs = loop(warmup, steps, True)
     sync()
     el = time.perf_counter() - t0
-    build_ms = sum(a.elapsed_time(b) for a, b in evs) / max(len(evs), 1)
-    return el, build_ms, float(loss.item()), (f"conditional GCN-VGAE+VQ train step on a minibatch stream: {fresh} resident minibatches round-robin, each step "
-                                              f"collates {G} graphs x {e} edges x {n} nodes on the device, builds both CSR pairs / transposes / gcn_norm / "
-                                              f"piece lists (one host read) and runs the optimizer step; in {args.in_dim}+{C}, latent {args.latent}, {args.codes} codes")
+    build_ms = sum(a.elapsed_time(b) for a, b in evs) / max(steps, 1)   # two event pairs per minibatch (begin, finish)
+    how = ("minibatches collated and built two ahead on a side stream while the steps run (MinibatchStream)" if prefetch
+           else "each step collates and builds on the step's own stream")
+    return el, build_ms, float(loss.item()), (f"conditional GCN-VGAE+VQ train step on a minibatch stream: {fresh} resident minibatches round-robin, {how}: "
+                                              f"{G} graphs x {e} edges x {n} nodes collated on the device, both CSR pairs / transposes / gcn_norm / "
+                                              f"piece lists (one host read), then the optimizer step; in {args.in_dim}+{C}, latent {args.latent}, {args.codes} codes")
 
 
 def gather_ceiling_ms(graph, x_like, F):
@@ -428,7 +428,8 @@ def main():
         if args.fresh_batches > 0:
             if args.scaling != "weak":
                 raise SystemExit("--fresh-batches: weak scaling only (every rank streams its own minibatches)")
-            el, build_ms, last_loss, wl = run_cvgae_stream(args, dev, args.steps, args.warmup, args.fresh_batches, rank, world, barrier)
+            el, build_ms, last_loss, wl = run_cvgae_stream(args, dev, args.steps, args.warmup, args.fresh_batches, rank, world, barrier,
+                                                           prefetch=args.prefetch)
         else:
             el, last_loss, wl = run_cvgae(args, dev, args.steps, args.warmup, rank, world, barrier)
         el, rep = rank_report(el, dev, world, backend)
@@ -625,6 +626,14 @@ def main():
                                         "steps": 20, "workload": wl_s, "loss": loss_s}
 
             leg("cvgae_stream", leg_stream)
+
+            def leg_stream_prefetch():
+                el_s, build_ms, loss_s, wl_s = run_cvgae_stream(args, dev, 20, 3, 4, prefetch=True)
+                line["cvgae_stream_prefetch"] = {"ms_per_step": el_s / 20 * 1e3, "graph_build_ms_overlapped": build_ms,
+                                                 "edges_per_s": args.graphs * args.edges_per_graph / (el_s / 20), "steps": 20, "workload": wl_s,
+                                                 "loss": loss_s}
+
+            leg("cvgae_stream_prefetch", leg_stream_prefetch)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

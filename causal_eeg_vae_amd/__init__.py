@@ -9,4 +9,4 @@ from .models import (  # noqa: F401
     ConditionalVGAEVQ, GATConv, negative_sampling, sigma_params,
 )
 from .conditioner import GraphConditioner  # noqa: F401
-from .collate import CollatedBatch, segment_ids  # noqa: F401
+from .collate import CollatedBatch, MinibatchStream, segment_ids  # noqa: F401

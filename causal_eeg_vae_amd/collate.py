@@ -6,6 +6,9 @@ counts, a `batch` vector with the graph id of every node, one `<key>_batch` vect
 back out of the collated storage with `torch_geometric.data.separate` (scripts/dataset.py:66-92).  Here the per-element work
 (offsetting, graph ids) is two HIP kernels over the already concatenated tensors (ceeg_collate_edges, ceeg_segment_ids);
 only the list of per-graph sizes is host data, as it is in PyG's `slice_dict`.
+
+`MinibatchStream` is the loader loop around it: minibatch k+1 is collated and its graph structures are built on a side HIP
+stream while the caller's optimizer step k runs on the current one.
 """
 import torch
 
@@ -60,7 +63,7 @@ class CollatedBatch:
             setattr(self, key + "_batch", self.followed[key][1])
             setattr(self, key + "_ptr", kp)
 
-    def event_graph(self, edge_weight=None, with_dec=True):
+    def event_graph(self, edge_weight=None, with_dec=True, defer=False):
         """The collated batch as an EventGraph, built with ONE host synchronisation (models.EventGraph: both CSR pairs, their
         piece lists and the layout check share one record).  For equal-sized graphs the check "no edge leaves its graph" is
         evaluated on the device and lands in graph.checks[("intra", nodes_per_graph)], which ConditionalVGAEVQ consults instead
@@ -73,8 +76,14 @@ class CollatedBatch:
             ei, eb = self.edge_index, self.edge_batch
             ok = ((ei[0] // n == eb) & (ei[1] // n == eb)).all() if ei.shape[1] else torch.ones((), dtype=torch.bool, device=ei.device)
             checks = {("intra", n): ok}
-        g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks)
+        g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks, defer=True)
         g.batch = self.batch
+        return g if defer else self.finish_graph(g)
+
+    @staticmethod
+    def finish_graph(g):
+        """Second half of event_graph(defer=True): the one host read + gcn_norm (models.EventGraph.finish)."""
+        g.finish()
         g.reuse = False          # a minibatch graph lives for one step: no per-graph packing of the value stream
         return g
 
@@ -97,3 +106,87 @@ class CollatedBatch:
         for key, (val, _, kp) in self.followed.items():
             parts[key] = val[int(kp[i]): int(kp[i + 1])]
         return out, n_hi - n_lo, parts
+
+
+class MinibatchStream:
+    """for collated, graph in MinibatchStream(minibatches): ... - the loop `for batch in train_dataloader`
+    (scripts/run.py:87-98,310) for minibatches whose per-graph edge lists are resident on the device.
+
+    `minibatches` yields (edge_indices, nodes_per_graph) or (edge_indices, nodes_per_graph, follow) (+ an optional 4th item,
+    the collated edge weights).  With prefetch=True (default) the construction runs on a SIDE stream, `depth` minibatches ahead
+    of the caller's optimizer steps on the current stream, in two halves: `begin` (collation, both CSR pairs, transposes, piece
+    lists, layout check, the record's asynchronous copy to pinned host memory - no host wait) when a minibatch enters the
+    window, `finish` (wait for the record, gcn_norm) right before it is handed out - by then the record has had a whole step to
+    land, so the host does not block.  Ordering rules the iterator enforces:
+      * the current stream waits for a minibatch's `finish` before the minibatch is handed out;
+      * a `begin` waits for the work the caller had queued on the current stream when it asked for the minibatch BEFORE the
+        one it is asking for now: the structures the caching allocator may hand to that `begin` (those of minibatches the
+        caller has dropped) are then no longer being read;
+      * the iterator keeps the minibatch it handed out last referenced until the next one has been handed out.
+    The inputs (edge lists, follow tensors) must be complete on the current stream when iteration starts.  prefetch=False is
+    the plain loop on the current stream.  `build_events` (timing=True): (start, end) event pairs, two per minibatch."""
+
+    def __init__(self, minibatches, with_dec=True, prefetch=True, depth=2, timing=False):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        self.minibatches, self.with_dec, self.prefetch, self.depth, self.timing = minibatches, bool(with_dec), bool(prefetch), int(depth), bool(timing)
+        self.build_events = []
+
+    def _timed(self, fn):
+        if not self.timing:
+            return fn()
+        s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn()
+        t.record()
+        self.build_events.append((s, t))
+        return out
+
+    def _begin(self, item):
+        def go():
+            cb = CollatedBatch(item[0], item[1], item[2] if len(item) > 2 else None)
+            return cb, cb.event_graph(edge_weight=item[3] if len(item) > 3 else None, with_dec=self.with_dec, defer=True)
+        return self._timed(go)
+
+    def _finish(self, cb, g):
+        return self._timed(lambda: (cb, CollatedBatch.finish_graph(g)))
+
+    def __iter__(self):
+        it = iter(self.minibatches)
+        if not self.prefetch:
+            for item in it:
+                yield self._finish(*self._begin(item))
+            return
+        from collections import deque
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=main.device)
+        side.wait_stream(main)
+        window = deque()
+        behind = None               # current-stream event behind the step in flight
+
+        for _ in range(self.depth):
+            item = next(it, None)
+            if item is None:
+                break
+            with torch.cuda.stream(side):
+                window.append(self._begin(item))
+        guard = None                # current-stream event behind the step BEFORE the one in flight
+        while window:
+            # Everything the side stream does from here on may allocate, and what the allocator hands out are the structures of
+            # minibatches the caller has dropped - the last of them was read by the step in front of `guard`.  The wait comes
+            # first and covers the `begin` and the `finish` below (also at the tail of the sequence, where there is no `begin`).
+            with torch.cuda.stream(side):
+                if guard is not None:
+                    side.wait_event(guard)
+                if behind is not None:
+                    item = next(it, None)
+                    if item is not None:
+                        window.append(self._begin(item))
+                cb, g = self._finish(*window.popleft())
+                done = torch.cuda.Event()
+                done.record(side)
+            guard = behind
+            main.wait_event(done)
+            yield cb, g
+            behind = torch.cuda.Event()
+            behind.record(main)     # the caller's step on (cb, g) is queued in front of this event

@@ -144,7 +144,7 @@ class EventGraph:
     synchronisation - what a loop that sees a new minibatch every step (scripts/run.py:310-326) wants.  Without them the decoder
     pair is built on first use (a second synchronisation)."""
 
-    def __init__(self, edge_index, num_nodes, edge_weight=None, with_dec=False, checks=None):
+    def __init__(self, edge_index, num_nodes, edge_weight=None, with_dec=False, checks=None, defer=False):
         self.edge_index = edge_index
         self.num_nodes = int(num_nodes)
         self.num_edges = int(edge_index.shape[1])
@@ -155,13 +155,32 @@ class EventGraph:
         parts = [self.gcn._rec] + ([self._dec._rec] if with_dec else [])
         if names:
             parts.append(torch.stack([checks[k].reshape(()).to(torch.int64) for k in names]))
-        rec = torch.cat(parts).cpu()            # the one host synchronisation of the construction
+        # the record starts its way to the host now (pinned buffer, asynchronous copy); finish() waits for it
+        rec_dev = torch.cat(parts)
+        rec_host = torch.empty(rec_dev.shape, dtype=torch.int64, pin_memory=True)
+        rec_host.copy_(rec_dev, non_blocking=True)
+        landed = torch.cuda.Event()
+        landed.record()
+        self._pending = (rec_host, landed, rec_dev, names, edge_weight, bool(with_dec))
+        if not defer:
+            self.finish()
+
+    def finish(self):
+        """Second half of the construction: wait for the record (the ONE host synchronisation), cut the arrays to the true entry
+        counts, gcn_norm.  `defer=True` leaves the call to a loader that has other work to queue first (collate.MinibatchStream);
+        it must run on the stream the construction was started on."""
+        if self._pending is None:
+            return self
+        rec_host, landed, _rec_dev, names, edge_weight, with_dec = self._pending
+        self._pending = None
+        landed.synchronize()
+        rec = rec_host
         self.gcn.finalize(rec[:6])
         if with_dec:
             self._dec.finalize(rec[6:12])
         self.checks = {k: bool(v) for k, v in zip(names, rec[len(rec) - len(names):].tolist())} if names else {}
         L = _lib.lib()
-        dev = edge_index.device
+        dev = self.edge_index.device
         ew = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
         self.dinv = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
         self.gcn_val = torch.empty(max(self.gcn.nnz, 1), dtype=torch.float32, device=dev)[: self.gcn.nnz]
@@ -172,6 +191,7 @@ class EventGraph:
         # val[t_perm[q]] (a dependent load in front of every row's gathers)
         self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
         self.reuse, self._gcn_cv, self._gcn_tcv = True, None, None
+        return self
 
     def cv(self, transposed=False):
         """(column, value) pairs of the normalised adjacency (or its transpose) interleaved into one int32 [nnz, 2] stream."""

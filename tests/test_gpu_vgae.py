@@ -990,6 +990,43 @@ def test_minibatch_stream_construction_equals_static_graph():
     assert torch.equal(l3, l4) and all(torch.equal(a, b) for a, b in zip(g3, g4))
 
 
+def test_minibatch_stream_prefetch_equals_serial_loop():
+    """collate.MinibatchStream: minibatches collated and built ahead on a side stream while the steps train on the current one.  Seven
+    optimizer steps over minibatches of different sizes (so that the allocator hands the structures of minibatch k to the build
+    of minibatch k+2) give the same graphs, losses and final parameters, bit for bit, as the plain loop on one stream."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ, MinibatchStream
+    from causal_eeg_vae_amd.trainer import Trainer
+    n, Fi, C, D, n_e = 300, 28, 4, 64, 64
+    sizes = [(5, 3000), (6, 2500), (4, 4100), (6, 2500), (5, 3000), (3, 5200), (6, 1800)]
+    mbs = [([torch.from_numpy(_graph(n, e, 100 * k + g)).cuda() for g in range(G)], [n] * G) for k, (G, e) in enumerate(sizes)]
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    feats = [(torch.randn(G * n, Fi, device="cuda", generator=gen), torch.randn(G, C, device="cuda", generator=gen)) for G, _ in sizes]
+
+    def train(prefetch):
+        torch.manual_seed(2)
+        model = ConditionalVGAEVQ(Fi, C, D, n_e, 0.25).cuda()
+        with torch.no_grad():
+            model.vector_quantization.embedding.weight.normal_(0, 0.3)
+        trainer = Trainer(model, lr=1e-2)
+        losses, structs = [], []
+        ms = MinibatchStream(mbs, prefetch=prefetch, timing=True)
+        for (cb, graph), (x, cond) in zip(ms, feats):
+            assert graph.checks == {("intra", n): True}
+            structs.append([t.clone() for t in (graph.gcn.rowptr, graph.gcn.col, graph.gcn.t_perm, graph.dec.t_col, graph.gcn_val, cb.batch)])
+            loss, _ = trainer.step(x, graph, cb.batch, cond, nodes_per_graph=n)
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        assert len(ms.build_events) == 2 * len(mbs) and all(a.elapsed_time(b) > 0 for a, b in ms.build_events)   # begin + finish
+        return losses, structs, [p.detach().clone() for p in model.parameters()]
+
+    l_a, s_a, p_a = train(False)
+    l_b, s_b, p_b = train(True)
+    assert all(torch.equal(a, b) for a, b in zip(l_a, l_b))
+    assert all(torch.equal(a, b) for sa, sb in zip(s_a, s_b) for a, b in zip(sa, sb))
+    assert all(torch.equal(a, b) for a, b in zip(p_a, p_b))
+    assert list(MinibatchStream([], prefetch=True)) == []
+
+
 @pytest.mark.parametrize("negatives", ["sigma", "uniform"])
 def test_bf16_step_vs_oracle_at_bf16_tolerance(negatives):
     """The opt-in reduced-precision step (VGAEVQ(compute_dtype=torch.bfloat16): bf16 storage of the encoder's activations, bf16
