@@ -626,14 +626,8 @@ def main():
                                         "steps": 20, "workload": wl_s, "loss": loss_s}
 
             leg("cvgae_stream", leg_stream)
-
-            def leg_stream_prefetch():
-                el_s, build_ms, loss_s, wl_s = run_cvgae_stream(args, dev, 20, 3, 4, prefetch=True)
-                line["cvgae_stream_prefetch"] = {"ms_per_step": el_s / 20 * 1e3, "graph_build_ms_overlapped": build_ms,
-                                                 "edges_per_s": args.graphs * args.edges_per_graph / (el_s / 20), "steps": 20, "workload": wl_s,
-                                                 "loss": loss_s}
-
-            leg("cvgae_stream_prefetch", leg_stream_prefetch)
+            # the side-stream loader (MinibatchStream, --prefetch) is measured by an explicit run
+            # (`--workload cvgae --fresh-batches 4 --prefetch`, profiles/r03_bench_cvgae_stream_prefetch.json), not in the default line
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)
