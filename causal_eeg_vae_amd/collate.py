@@ -171,7 +171,7 @@ class MinibatchStream:
             with torch.cuda.stream(side):
                 window.append(self._begin(item))
         guard = None                # current-stream event behind the step BEFORE the one in flight
-        while window:
+        while True:
             # Everything the side stream does from here on may allocate, and what the allocator hands out are the structures of
             # minibatches the caller has dropped - the last of them was read by the step in front of `guard`.  The wait comes
             # first and covers the `begin` and the `finish` below (also at the tail of the sequence, where there is no `begin`).
@@ -182,6 +182,8 @@ class MinibatchStream:
                     item = next(it, None)
                     if item is not None:
                         window.append(self._begin(item))
+                if not window:
+                    return
                 cb, g = self._finish(*window.popleft())
                 done = torch.cuda.Event()
                 done.record(side)

@@ -1027,6 +1027,32 @@ def test_minibatch_stream_prefetch_equals_serial_loop():
     assert list(MinibatchStream([], prefetch=True)) == []
 
 
+@pytest.mark.parametrize("prefetch,depth", [(False, 1), (True, 1), (True, 3)])
+def test_minibatch_stream_follow_keys_and_edge_weights(prefetch, depth):
+    """MinibatchStream items with followed keys and collated edge weights give what CollatedBatch(...).event_graph(edge_weight)
+    gives directly (any window depth, also deeper than the sequence is long)."""
+    from causal_eeg_vae_amd import CollatedBatch, MinibatchStream
+    n = 120
+    items, direct = [], []
+    for k, (G, e) in enumerate([(3, 900), (2, 1500), (4, 700), (1, 50)]):
+        eis = [torch.from_numpy(_graph(n, e, 300 + 10 * k + g)).cuda() for g in range(G)]
+        follow = {"tok": [torch.full((g + 2, 3), float(10 * k + g), device="cuda") for g in range(G)]}
+        w = torch.rand(G * e, device="cuda") + 0.5
+        items.append((eis, [n] * G, follow, w))
+        cb = CollatedBatch(eis, [n] * G, follow)
+        direct.append((cb, cb.event_graph(edge_weight=w)))
+    got = list(MinibatchStream(items, prefetch=prefetch, depth=depth))
+    torch.cuda.synchronize()
+    assert len(got) == len(direct)
+    for (cb, g), (cb0, g0) in zip(got, direct):
+        assert torch.equal(cb.edge_index, cb0.edge_index) and torch.equal(cb.batch, cb0.batch)
+        assert torch.equal(cb.tok, cb0.tok) and torch.equal(cb.tok_batch, cb0.tok_batch)
+        assert g.checks == g0.checks and g.reuse is False
+        for a, b in ((g.gcn.rowptr, g0.gcn.rowptr), (g.gcn.col, g0.gcn.col), (g.gcn.t_perm, g0.gcn.t_perm), (g.gcn_val, g0.gcn_val),
+                     (g.gcn_tval, g0.gcn_tval), (g.dinv, g0.dinv), (g.dec.col, g0.dec.col)):
+            assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("negatives", ["sigma", "uniform"])
 def test_bf16_step_vs_oracle_at_bf16_tolerance(negatives):
     """The opt-in reduced-precision step (VGAEVQ(compute_dtype=torch.bfloat16): bf16 storage of the encoder's activations, bf16
