@@ -173,7 +173,7 @@ def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
     model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
     with torch.no_grad():
         model.vector_quantization.embedding.weight.normal_(0, 0.1)
-    trainer = Trainer(model, lr=1e-3, world_size=world)
+    trainer = Trainer(model, lr=1e-3, world_size=world, force_exchange=FORCE_DIST)
     sync = barrier or torch.cuda.synchronize
     for _ in range(warmup):
         trainer.step(x, graph, batch, cond, nodes_per_graph=n)
@@ -207,7 +207,7 @@ def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=N
     model = ConditionalVGAEVQ(args.in_dim, C, args.latent, args.codes, 0.25, seed=rank).to(dev)
     with torch.no_grad():
         model.vector_quantization.embedding.weight.normal_(0, 0.1)
-    trainer = Trainer(model, lr=1e-3, world_size=world)
+    trainer = Trainer(model, lr=1e-3, world_size=world, force_exchange=FORCE_DIST)
     sync = barrier or torch.cuda.synchronize
     sizes = [n] * G
     from causal_eeg_vae_amd.collate import MinibatchStream
@@ -263,15 +263,20 @@ def gather_ceiling_ms(graph, x_like, F):
     return out
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def launch_ranks(n, argv, script=None, timeout=None):
     """`python bench.py --gpus N` without a launcher around it (N > 1, WORLD_SIZE unset): start N fresh ranks with
     torch.distributed.run as CHILD processes - this process has made no GPU call and makes none -, relay rank 0's JSON line
     as this process's last stdout line and return the children's exit code (non-zero when any rank failed or no line came).
     Everything else the ranks print goes to stderr."""
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
+    port = _free_port()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -306,11 +311,17 @@ def launch_ranks(n, argv, script=None, timeout=None):
     return 0
 
 
+# CEEG_FORCE_DIST=1: a ONE-rank process group on the real backend (RCCL) with every collective of the N-rank path issued -
+# parameter broadcast, the per-step flat all-reduce, barriers, the report's all-gather.  Two RCCL ranks cannot share a device, so
+# on a one-GPU box this is as far as RCCL itself can be exercised (profiles/r03_rehearsal_rccl_1rank.json).
+FORCE_DIST = os.environ.get("CEEG_FORCE_DIST") == "1"
+
+
 def rank_report(el, dev, world, backend):
     """What the process group saw, so an N-rank record checks itself: ranks, backend, the device every rank ran on and the
     per-rank time of the timed region.  Returns (max el over ranks, dict) on every rank."""
     idx = dev.index if dev.index is not None else 0
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return el, {"ranks": 1, "backend": None, "devices": [idx]}
     t = torch.tensor([el, float(idx)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     out = [torch.empty_like(t) for _ in range(world)]
@@ -351,11 +362,14 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or FORCE_DIST:
+        kw = {}
+        if "WORLD_SIZE" not in os.environ:      # CEEG_FORCE_DIST without a launcher: a one-rank group of our own
+            kw = {"init_method": f"tcp://127.0.0.1:{_free_port()}", "world_size": 1, "rank": 0}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     verbose = os.environ.get("CEEG_BENCH_VERBOSE") == "1"
 
@@ -373,7 +387,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -443,7 +457,7 @@ def main():
                 line["graph_build_ms"] = build_ms
             line.update(_finish_report(rep, args.steps))
             print(json.dumps(line))
-        if world > 1:
+        if world > 1 or FORCE_DIST:
             dist.destroy_process_group()
         return
 
@@ -457,7 +471,7 @@ def main():
     with torch.no_grad():
         model.vector_quantization.embedding.weight.normal_(0, 0.1)
     note("graph built")
-    trainer = Trainer(model, lr=1e-3, world_size=world)
+    trainer = Trainer(model, lr=1e-3, world_size=world, force_exchange=FORCE_DIST)
     note("parameters broadcast")
 
     for _ in range(args.warmup):
@@ -634,7 +648,7 @@ def main():
             except Exception as ex:  # noqa: BLE001
                 line.setdefault("extras_failed", {})["cpu_baseline"] = f"{type(ex).__name__}: {ex}"[:400]
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or FORCE_DIST:
         dist.destroy_process_group()
 
 

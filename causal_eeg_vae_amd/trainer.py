@@ -5,8 +5,9 @@ import torch
 import torch.distributed as dist
 
 
-def allreduce_grads_(params, world_size):
-    """Average gradients across ranks with ONE flat all-reduce (sum) followed by 1/world_size.
+def allreduce_grads_(params, world_size, force=False):
+    """Average gradients across ranks with ONE flat all-reduce (sum) followed by 1/world_size.  force=True runs the exchange
+    on a one-rank group too (rehearsal of the collective path on a single GPU).
 
     Correct by construction for either backend:
       * `nccl` (= RCCL): the collective is enqueued behind the backward's kernels (ProcessGroupNCCL makes its stream wait on
@@ -18,7 +19,7 @@ def allreduce_grads_(params, world_size):
         (Round 1: two ranks sharing one GPU dead-locked in the SECOND gloo all-reduce of a device tensor, both main threads
         inside work.wait(); DESIGN.md section 6 has what the trace does and does not show.)"""
     grads = [p.grad for p in params if p.grad is not None]
-    if not grads or world_size <= 1:
+    if not grads or (world_size <= 1 and not force):
         return
     if len(grads) != len(params):
         # every rank must reduce the same bucket layout: a parameter without a gradient on one rank only would silently
@@ -51,9 +52,10 @@ def broadcast_params_(module, src=0):
 
 
 class Trainer:
-    def __init__(self, model, lr=1e-3, world_size=1):
+    def __init__(self, model, lr=1e-3, world_size=1, force_exchange=False):
         self.model = model
         self.world_size = int(world_size)
+        self.force_exchange = bool(force_exchange)   # broadcast + all-reduce even with one rank (one-GPU RCCL rehearsal)
         self.params = [p for p in model.parameters() if p.requires_grad]
         if any(p.is_cuda for p in self.params):
             from . import _lib
@@ -62,7 +64,7 @@ class Trainer:
         self.opt = torch.optim.Adam(self.params, lr=lr, fused=all(p.is_cuda for p in self.params))
         self.sched = torch.optim.lr_scheduler.ReduceLROnPlateau(self.opt)  # scripts/run.py:57 (defaults)
         self.step_idx = 0
-        if self.world_size > 1:
+        if self.world_size > 1 or self.force_exchange:
             broadcast_params_(model)
 
     def end_epoch(self, val_loss):
@@ -75,7 +77,7 @@ class Trainer:
         self.opt.zero_grad(set_to_none=True)                 # scripts/run.py:87
         loss, aux = self.model(x, graph, *model_args, step=self.step_idx, eps=eps, **model_kwargs)  # scripts/run.py:89-95
         loss.backward()                                      # scripts/run.py:96
-        allreduce_grads_(self.params, self.world_size)
+        allreduce_grads_(self.params, self.world_size, self.force_exchange)
         self.opt.step()                                      # scripts/run.py:97
         self.step_idx += 1
         return loss.detach(), aux                            # no host sync here (run.py:98 syncs every step)
