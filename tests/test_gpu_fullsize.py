@@ -371,3 +371,37 @@ def test_config2_dense_products_with_the_tuned_table(n_in, n_out, relu):
     ratio = float(((dw.double() - dw64).abs() / dwabs).max())
     print(f"dW: max |err| / sum|terms| = {ratio:.3e}")
     assert ratio <= 1e-7
+
+
+def test_config4_minibatch_structures_derived_equal_sorted(monkeypatch):
+    """BASELINE configs[3] at full size (64 graphs x 100 k edges x 6250 nodes, collated on the device): the A + I pair derived
+    from the raw-edge pair (ceeg_csr_add_self_loops) equals the one built by its own sort and transpose, array for array, and
+    the structural properties hold: one loop entry per node, sorted rows, t_perm a permutation that maps every transposed entry
+    to the forward entry with swapped endpoints."""
+    from causal_eeg_vae_amd import CollatedBatch
+    from causal_eeg_vae_amd.synth import synth_event_graph
+    G, n, e = 64, 6250, 100000
+    eis = [synth_event_graph(n, e, seed=4096 * 7 + g, device="cuda") for g in range(G)]
+    eis[3][:, :50] = eis[3][0, :50]                           # 50 input self-loops (several per node) in one graph
+    cb = CollatedBatch(eis, [n] * G)
+    monkeypatch.setenv("CEEG_GCN_FROM_RAW", "1")
+    a = cb.event_graph()
+    monkeypatch.setenv("CEEG_GCN_FROM_RAW", "0")
+    b = cb.event_graph()
+    N = G * n
+    assert a.gcn.nnz == b.gcn.nnz and a.gcn.max_row == b.gcn.max_row and a.gcn.max_trow == b.gcn.max_trow
+    for name in ("rowptr", "col", "perm", "t_rowptr", "t_col", "t_perm"):
+        assert torch.equal(getattr(a.gcn, name), getattr(b.gcn, name)), name
+    for t in (False, True):
+        ia, ib = a.gcn.long_items(t), b.gcn.long_items(t)
+        assert (ia is None and ib is None) or torch.equal(ia, ib)
+    assert torch.equal(a.gcn_val, b.gcn_val) and torch.equal(a.gcn_tval, b.gcn_tval)
+    p = a.gcn
+    rows = torch.repeat_interleave(torch.arange(N, device="cuda"), (p.rowptr[1:] - p.rowptr[:-1]).long())
+    assert int((p.col.long() == rows).sum()) == N                                  # exactly one loop entry per node ...
+    assert p.nnz == a.dec.nnz - 50 + N                                            # ... and the 50 input loops are gone
+    key = rows * N + p.col.long()
+    assert bool((key[1:] >= key[:-1]).all())                                       # (row, col) ascending
+    assert torch.equal(torch.sort(p.t_perm.long()).values, torch.arange(p.nnz, device="cuda"))
+    t_rows = torch.repeat_interleave(torch.arange(N, device="cuda"), (p.t_rowptr[1:] - p.t_rowptr[:-1]).long())
+    assert torch.equal(p.col.long()[p.t_perm.long()], t_rows) and torch.equal(rows[p.t_perm.long()], p.t_col.long())
