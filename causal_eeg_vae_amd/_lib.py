@@ -33,6 +33,7 @@ SIGNATURES = {
     "ceeg_csr_transpose_ws_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ceeg_csr_transpose": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_gcn_norm": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp]),
+    "ceeg_gcn_norm_t": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ceeg_csr_long_items_ws_bytes": (_c_sz, [_c_i64]),
     "ceeg_csr_long_items": (_c_int, [_vp, _c_i64, _c_int, _vp, _c_i64, _vp, _vp, _c_sz, _vp]),
     "ceeg_csr_add_self_loops_ws_bytes": (_c_sz, [_c_i64]),
@@ -92,6 +93,7 @@ SIGNATURES = {
                                           _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_segment_ids": (_c_int, [_vp, _c_i64, _c_i64, _vp, _vp]),
     "ceeg_collate_edges": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _c_int, _vp, _c_i64, _vp, _vp]),
+    "ceeg_collate_edges_checked": (_c_int, [_vp, _c_i64, _vp, _vp, _c_i64, _c_i64, _vp, _c_i64, _vp, _vp, _vp]),
     "ceeg_top_predecessors": (_c_int, [_vp, _vp, _vp, _vp, _c_i64, _c_int, _c_i64, _vp, _vp]),
     "ceeg_ancestors_cap": (_c_int, [_c_int, _c_int]),
     "ceeg_ancestors": (_c_int, [_vp, _c_i64, _c_int, _vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp]),

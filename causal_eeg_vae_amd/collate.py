@@ -48,9 +48,11 @@ class CollatedBatch:
         E = raw.shape[1]
         self.edge_index = torch.empty_like(raw)
         self.edge_batch = torch.empty(max(E, 1), dtype=torch.int64, device=dev)[:E]
-        _lib.check(_lib.lib().ceeg_collate_edges(raw.data_ptr(), raw.stride(0), self.edge_ptr.data_ptr(), self.ptr.data_ptr(), G, E, 1,
-                                                 self.edge_index.data_ptr(), self.edge_index.stride(0), self.edge_batch.data_ptr(), _lib.stream()),
-                   "ceeg_collate_edges")
+        # `outside` (device int32): 1 if some edge does not stay inside its graph's block of node ids - written by the same kernel
+        self.outside = torch.empty(1, dtype=torch.int32, device=dev)
+        _lib.check(_lib.lib().ceeg_collate_edges_checked(raw.data_ptr(), raw.stride(0), self.edge_ptr.data_ptr(), self.ptr.data_ptr(), G, E,
+                                                         self.edge_index.data_ptr(), self.edge_index.stride(0), self.edge_batch.data_ptr(),
+                                                         self.outside.data_ptr(), _lib.stream()), "ceeg_collate_edges_checked")
         self.batch = segment_ids(self.ptr, self.num_nodes)
         self.followed = {}
         for key, parts in (follow or {}).items():          # follow_batch=[key, ...]: rows of `key` belong to their sample's graph
@@ -73,9 +75,7 @@ class CollatedBatch:
         sizes = set(self.nodes_per_graph)
         if len(sizes) == 1 and self.nodes_per_graph[0] > 0:
             n = int(self.nodes_per_graph[0])
-            ei, eb = self.edge_index, self.edge_batch
-            ok = ((ei[0] // n == eb) & (ei[1] // n == eb)).all() if ei.shape[1] else torch.ones((), dtype=torch.bool, device=ei.device)
-            checks = {("intra", n): ok}
+            checks = {("intra", n): self.outside[0] == 0}
         g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks, defer=True)
         g.batch = self.batch
         return g if defer else self.finish_graph(g)

@@ -335,7 +335,8 @@ __global__ __launch_bounds__(256) void csr_piece_count_kernel(const int32_t* __r
   __syncthreads();
   if (threadIdx.x == 0) {
     m = max(max(red[0], red[1]), max(red[2], red[3]));
-    if (m > 0) atomicMax(&rec[1], (unsigned long long)m);  // integer max: order-independent
+    // integer max: order-independent; the plain read only skips atomics that could not raise the value (it never decreases)
+    if (m > 0 && (unsigned long long)m > *reinterpret_cast<volatile unsigned long long*>(&rec[1])) atomicMax(&rec[1], (unsigned long long)m);
   }
 }
 __global__ __launch_bounds__(256) void csr_piece_fill_kernel(const int32_t* __restrict__ rowptr, int64_t N, int chunk,
@@ -422,15 +423,17 @@ __global__ __launch_bounds__(256) void csr_loops_count_kernel(const int32_t* __r
 
 // 16 lanes per row.  TRANSPOSED = false: (col, perm) are the raw CSR's columns and edge ids, the loop entry gets the last dropped
 // loop's edge id or -1.  TRANSPOSED = true: (col, perm) are the raw transpose's (t_col, t_perm); an entry's t_perm becomes its
-// position in the NEW forward CSR (f_* = the raw forward row pointers, g_rowptr = the new ones, f_lt = loop position inside a
-// forward row), the loop entry of row r points at the forward loop entry of row r.
+// position in the NEW forward CSR (info[c] = shift of forward row c's start and of its entries behind the loop, written by the
+// forward pass; g_rowptr = the new forward row pointers, f_lt = loop position inside a forward row), the loop entry of row r
+// points at the forward loop entry of row r.
 template <bool TRANSPOSED>
 __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                              const int32_t* __restrict__ perm, const int32_t* __restrict__ lt,
                                                              const int32_t* __restrict__ loops_scan /* exclusive, N + 1 */, int64_t N,
-                                                             const int32_t* __restrict__ f_rowptr, const int32_t* __restrict__ f_lt,
-                                                             const int32_t* __restrict__ g_rowptr, int32_t* __restrict__ o_rowptr,
-                                                             int32_t* __restrict__ o_col, int32_t* __restrict__ o_perm) {
+                                                             int2* __restrict__ info /* forward: written; transposed: read */,
+                                                             const int32_t* __restrict__ f_lt, const int32_t* __restrict__ g_rowptr,
+                                                             int32_t* __restrict__ o_rowptr, int32_t* __restrict__ o_col,
+                                                             int32_t* __restrict__ o_perm) {
   const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   if (r >= N) return;
   const int l = threadIdx.x & 15;
@@ -441,8 +444,12 @@ __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __re
     o_rowptr[r] = base;
     if (r == N - 1) o_rowptr[N] = hi - loops_scan[N] + (int)N;
     o_col[base + a] = (int32_t)r;
-    if constexpr (TRANSPOSED) o_perm[base + a] = g_rowptr[r] + f_lt[r];
-    else o_perm[base + a] = nl > 0 ? perm[lo + a + nl - 1] : -1;
+    if constexpr (TRANSPOSED) {
+      o_perm[base + a] = g_rowptr[r] + f_lt[r];
+    } else {
+      o_perm[base + a] = nl > 0 ? perm[lo + a + nl - 1] : -1;
+      info[r] = make_int2(base - lo, 1 - nl);  // what the transposed side needs of this row, in one 8-byte read per entry
+    }
   }
   for (int p = lo + l; p < hi; p += 16) {
     const int k = p - lo;
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __re
     o_col[q] = c;
     if constexpr (TRANSPOSED) {
       const int fp = perm[p];                       // position in the raw forward CSR, in forward row c, whose column is r
-      const int fnl = loops_scan[c + 1] - loops_scan[c];
-      o_perm[q] = g_rowptr[c] + (fp - f_rowptr[c]) + ((int32_t)r > c ? 1 - fnl : 0);
+      const int2 fi = info[c];                      // (new - old start of forward row c, 1 - its dropped loops)
+      o_perm[q] = fp + fi.x + ((int32_t)r > c ? fi.y : 0);
     } else {
       o_perm[q] = perm[p];
     }
@@ -463,7 +470,7 @@ __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __re
 
 extern "C" size_t ceeg_csr_add_self_loops_ws_bytes(int64_t N) {
   if (N <= 0) return 0;
-  return 4 * ceeg_ws_part((size_t)N + 1, 4) + ceeg_align_up(piece_scan_temp(N + 1), 256);
+  return 4 * ceeg_ws_part((size_t)N + 1, 4) + ceeg_ws_part((size_t)N + 1, 8) + ceeg_align_up(piece_scan_temp(N + 1), 256);
 }
 
 extern "C" int ceeg_csr_add_self_loops(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const int32_t* t_rowptr,
@@ -482,6 +489,7 @@ extern "C" int ceeg_csr_add_self_loops(const int32_t* rowptr, const int32_t* col
   int32_t* t_lt = a.take<int32_t>((size_t)N + 1);
   int32_t* loops = a.take<int32_t>((size_t)N + 1);
   int32_t* scan = a.take<int32_t>((size_t)N + 1);
+  int2* info = a.take<int2>((size_t)N + 1);
   size_t tb = piece_scan_temp(N + 1);
   void* temp = a.take<char>(tb);
   if (!a.ok) return CEEG_EWORKSPACE;
@@ -491,11 +499,30 @@ extern "C" int ceeg_csr_add_self_loops(const int32_t* rowptr, const int32_t* col
   hipLaunchKernelGGL(csr_loops_count_kernel, rows, dim3(256), 0, st, t_rowptr, t_col, N, t_lt, static_cast<int32_t*>(nullptr));
   CEEG_CHECK_LAUNCH();
   if (rocprim::exclusive_scan(temp, tb, loops, scan, 0, (size_t)N + 1, rocprim::plus<int32_t>(), st, false) != hipSuccess) return CEEG_ELAUNCH;
-  hipLaunchKernelGGL(csr_loops_fill_kernel<false>, groups, dim3(256), 0, st, rowptr, col, perm, lt, scan, N, static_cast<const int32_t*>(nullptr),
+  hipLaunchKernelGGL(csr_loops_fill_kernel<false>, groups, dim3(256), 0, st, rowptr, col, perm, lt, scan, N, info,
                      static_cast<const int32_t*>(nullptr), static_cast<const int32_t*>(nullptr), g_rowptr, g_col, g_perm);
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(csr_loops_fill_kernel<true>, groups, dim3(256), 0, st, t_rowptr, t_col, t_perm, t_lt, scan, N, rowptr, lt, g_rowptr, gt_rowptr,
+  hipLaunchKernelGGL(csr_loops_fill_kernel<true>, groups, dim3(256), 0, st, t_rowptr, t_col, t_perm, t_lt, scan, N, info, lt, g_rowptr, gt_rowptr,
                      gt_col, gt_perm);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+namespace {
+__global__ void gcn_tval_kernel(const int32_t* __restrict__ t_rowptr, const int32_t* __restrict__ t_perm, const float* __restrict__ val,
+                                int64_t N, int64_t cap, float* __restrict__ tval) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < cap && q < t_rowptr[N]) tval[q] = val[t_perm[q]];
+}
+}  // namespace
+
+extern "C" int ceeg_gcn_norm_t(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew, int64_t nnz, int64_t N,
+                               float* deg_inv_sqrt, float* val, const int32_t* t_rowptr, const int32_t* t_perm, float* tval, void* stream) {
+  if (!t_rowptr || (nnz > 0 && (!t_perm || !tval))) return CEEG_EINVAL;
+  const int rc = ceeg_gcn_norm(rowptr, col, perm, ew, nnz, N, deg_inv_sqrt, val, stream);
+  if (rc != CEEG_OK || nnz == 0) return rc;
+  hipLaunchKernelGGL(gcn_tval_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), t_rowptr, t_perm, val, N,
+                     nnz, tval);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
@@ -570,14 +597,19 @@ __global__ void segment_ids_kernel(const int64_t* __restrict__ ptr, int G, int64
 }
 __global__ void collate_edges_kernel(const int64_t* __restrict__ in, int64_t ld_in, const int64_t* __restrict__ edge_ptr,
                                      const int64_t* __restrict__ node_ptr, int G, int64_t E, int sign, int64_t* __restrict__ out,
-                                     int64_t ld_out, int64_t* __restrict__ edge_batch) {
+                                     int64_t ld_out, int64_t* __restrict__ edge_batch, int32_t* __restrict__ outside) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
   const int g = seg_of(edge_ptr, G, e);
   const int64_t off = sign * node_ptr[g];
-  out[e] = in[e] + off;
-  out[ld_out + e] = in[ld_in + e] + off;
+  const int64_t s = in[e], d = in[ld_in + e];
+  out[e] = s + off;
+  out[ld_out + e] = d + off;
   if (edge_batch) edge_batch[e] = g;
+  if (outside) {  // an endpoint that is not a local id of graph g: the collated edge leaves its graph's block (integer OR: order-independent)
+    const int64_t n = node_ptr[g + 1] - node_ptr[g];
+    if (s < 0 || s >= n || d < 0 || d >= n) atomicOr(outside, 1);
+  }
 }
 }  // namespace
 
@@ -595,7 +627,22 @@ extern "C" int ceeg_collate_edges(const int64_t* edges_in, int64_t ld_in, const 
   if (E == 0) return CEEG_OK;
   if (!edges_in || !edges_out || ld_in < E || ld_out < E) return CEEG_EINVAL;
   hipLaunchKernelGGL(collate_edges_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), edges_in, ld_in,
-                     edge_ptr, node_ptr, (int)G, E, sign, edges_out, ld_out, edge_batch);
+                     edge_ptr, node_ptr, (int)G, E, sign, edges_out, ld_out, edge_batch, static_cast<int32_t*>(nullptr));
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
+// ceeg_collate_edges (sign = +1) that also reports whether every edge stays inside its graph: *outside (int32 on the device) is set
+// to 0 and then to 1 if some endpoint is not a local id of its graph.
+extern "C" int ceeg_collate_edges_checked(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
+                                          int64_t E, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, int32_t* outside, void* stream) {
+  if (!edge_ptr || !node_ptr || !outside || G <= 0 || E < 0 || G >= ((int64_t)1 << 31)) return CEEG_EINVAL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(outside, 0, sizeof(int32_t), st) != hipSuccess) return CEEG_ELAUNCH;
+  if (E == 0) return CEEG_OK;
+  if (!edges_in || !edges_out || ld_in < E || ld_out < E) return CEEG_EINVAL;
+  hipLaunchKernelGGL(collate_edges_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, edges_in, ld_in, edge_ptr, node_ptr, (int)G, E, 1,
+                     edges_out, ld_out, edge_batch, outside);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }

@@ -184,12 +184,12 @@ class EventGraph:
         ew = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()
         self.dinv = torch.empty(self.num_nodes, dtype=torch.float32, device=dev)
         self.gcn_val = torch.empty(max(self.gcn.nnz, 1), dtype=torch.float32, device=dev)[: self.gcn.nnz]
-        _lib.check(L.ceeg_gcn_norm(self.gcn.rowptr.data_ptr(), self.gcn.col.data_ptr(), self.gcn.perm.data_ptr(), _lib.ptr(ew),
-                                   self.gcn.nnz, self.num_nodes, self.dinv.data_ptr(), self.gcn_val.data_ptr(), _lib.stream()),
-                   "ceeg_gcn_norm")
-        # values in the transposed order, gathered once: the backward SpMM then streams them instead of chasing
+        # values also in the transposed order, gathered once (same call): the backward SpMM then streams them instead of chasing
         # val[t_perm[q]] (a dependent load in front of every row's gathers)
-        self.gcn_tval = self.gcn_val[self.gcn.t_perm.long()] if self.gcn.nnz else self.gcn_val
+        self.gcn_tval = torch.empty(max(self.gcn.nnz, 1), dtype=torch.float32, device=dev)[: self.gcn.nnz]
+        _lib.check(L.ceeg_gcn_norm_t(self.gcn.rowptr.data_ptr(), self.gcn.col.data_ptr(), self.gcn.perm.data_ptr(), _lib.ptr(ew),
+                                     self.gcn.nnz, self.num_nodes, self.dinv.data_ptr(), self.gcn_val.data_ptr(), self.gcn.t_rowptr.data_ptr(),
+                                     self.gcn.t_perm.data_ptr(), self.gcn_tval.data_ptr(), _lib.stream()), "ceeg_gcn_norm_t")
         self.reuse, self._gcn_cv, self._gcn_tcv = True, None, None
         return self
 

@@ -134,6 +134,10 @@ int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, i
                        void* ws, size_t ws_bytes, void* stream);
 int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew,
                   int64_t nnz, int64_t N, float* deg_inv_sqrt, float* val, void* stream);
+/* ceeg_gcn_norm followed by the values in the transposed structure's order, tval[q] = val[t_perm[q]] for q < t_rowptr[N] (what the
+ * backward aggregation streams); `nnz` may be a capacity as above. */
+int ceeg_gcn_norm_t(const int32_t* rowptr, const int32_t* col, const int32_t* perm, const float* ew, int64_t nnz, int64_t N,
+                    float* deg_inv_sqrt, float* val, const int32_t* t_rowptr, const int32_t* t_perm, float* tval, void* stream);
 /* What host code must know about a freshly built CSR before it can launch on it, produced on the DEVICE in one small record so
  * that a graph built inside the training loop (a new PyG minibatch every step, scripts/run.py:310-326) costs ONE host read:
  *   record[0] = rowptr[N] (the entry count; ceeg_csr_transpose and ceeg_gcn_norm accept a capacity >= it as their `nnz`, the
@@ -486,6 +490,11 @@ int ceeg_graph_layernorm_bwd(const float* g, int64_t ldg, const float* x, int64_
 int ceeg_segment_ids(const int64_t* ptr, int64_t G, int64_t total, int64_t* out, void* stream);
 int ceeg_collate_edges(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
                        int64_t E, int sign, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, void* stream);
+/* ceeg_collate_edges with sign = +1 that also answers "does every edge stay inside its graph" on the device: *outside (one int32)
+ * becomes 0, then 1 if some endpoint is not a local id in [0, node_ptr[g+1] - node_ptr[g]) of its graph g.  The per-graph negative
+ * sampling of the conditional model (scripts/models.py:259 on a collated batch) relies on that layout. */
+int ceeg_collate_edges_checked(const int64_t* edges_in, int64_t ld_in, const int64_t* edge_ptr, const int64_t* node_ptr, int64_t G,
+                               int64_t E, int64_t* edges_out, int64_t ld_out, int64_t* edge_batch, int32_t* outside, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * N3  Ancestor-subgraph extraction of the reference's dataset builder for ALL targets at once (scripts/dataset.py:22-46,
