@@ -41,8 +41,12 @@ class CollatedBatch:
         _lib.require_cuda(*edge_indices)
         self.num_graphs = G = len(edge_indices)
         self.nodes_per_graph = [int(n) for n in nodes_per_graph]
-        self.ptr = _ptr(nodes_per_graph, dev)
-        self.edge_ptr = _ptr([int(e.shape[1]) for e in edge_indices], dev)
+        # both slice tables in ONE pinned buffer and one asynchronous copy (two pageable copies cost the loader loop ~0.1 ms of idle GPU)
+        host = torch.zeros(2, G + 1, dtype=torch.int64, pin_memory=True)
+        host[0, 1:] = torch.as_tensor(self.nodes_per_graph, dtype=torch.int64).cumsum(0)
+        host[1, 1:] = torch.as_tensor([int(e.shape[1]) for e in edge_indices], dtype=torch.int64).cumsum(0)
+        both = host.to(dev, non_blocking=True)
+        self.ptr, self.edge_ptr = both[0], both[1]
         self.num_nodes = int(sum(int(n) for n in nodes_per_graph))
         raw = torch.cat([e.to(torch.int64) for e in edge_indices], dim=1).contiguous()   # one concatenation, no per-graph arithmetic
         E = raw.shape[1]
@@ -113,7 +117,8 @@ class MinibatchStream:
     (scripts/run.py:87-98,310) for minibatches whose per-graph edge lists are resident on the device.
 
     `minibatches` yields (edge_indices, nodes_per_graph) or (edge_indices, nodes_per_graph, follow) (+ an optional 4th item,
-    the collated edge weights).  With prefetch=True (default) the construction runs on a SIDE stream, `depth` minibatches ahead
+    the collated edge weights).  prefetch=False (default) is the plain loop on the current stream.  With prefetch=True the
+    construction runs on a SIDE stream, `depth` minibatches ahead
     of the caller's optimizer steps on the current stream, in two halves: `begin` (collation, both CSR pairs, transposes, piece
     lists, layout check, the record's asynchronous copy to pinned host memory - no host wait) when a minibatch enters the
     window, `finish` (wait for the record, gcn_norm) right before it is handed out - by then the record has had a whole step to
@@ -123,10 +128,11 @@ class MinibatchStream:
         one it is asking for now: the structures the caching allocator may hand to that `begin` (those of minibatches the
         caller has dropped) are then no longer being read;
       * the iterator keeps the minibatch it handed out last referenced until the next one has been handed out.
-    The inputs (edge lists, follow tensors) must be complete on the current stream when iteration starts.  prefetch=False is
-    the plain loop on the current stream.  `build_events` (timing=True): (start, end) event pairs, two per minibatch."""
+    The inputs (edge lists, follow tensors) must be complete on the current stream when iteration starts.  Which one is faster is a
+    measurement: the overlap hides the host's one read and the launch gaps of the construction but its sorts compete with the
+    step for the memory system (config 4 on an MI355X: 6.88 ms/step against 6.79 for the plain loop).  `build_events` (timing=True): (start, end) event pairs, two per minibatch."""
 
-    def __init__(self, minibatches, with_dec=True, prefetch=True, depth=2, timing=False):
+    def __init__(self, minibatches, with_dec=True, prefetch=False, depth=2, timing=False):
         if depth < 1:
             raise ValueError("depth >= 1")
         self.minibatches, self.with_dec, self.prefetch, self.depth, self.timing = minibatches, bool(with_dec), bool(prefetch), int(depth), bool(timing)
