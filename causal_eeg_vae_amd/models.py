@@ -193,6 +193,11 @@ class EventGraph:
         self.reuse, self._gcn_cv, self._gcn_tcv = True, None, None
         return self
 
+    def __getattr__(self, name):   # only reached for attributes that are not there
+        if name in ("gcn_val", "gcn_tval", "dinv", "checks", "reuse") and self.__dict__.get("_pending") is not None:
+            raise _lib.CeegError(f"EventGraph.{name}: the graph was built with defer=True and finish() has not been called")
+        raise AttributeError(name)
+
     def cv(self, transposed=False):
         """(column, value) pairs of the normalised adjacency (or its transpose) interleaved into one int32 [nnz, 2] stream."""
         if transposed:

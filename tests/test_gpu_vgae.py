@@ -1041,6 +1041,12 @@ def test_minibatch_stream_follow_keys_and_edge_weights(prefetch, depth):
         items.append((eis, [n] * G, follow, w))
         cb = CollatedBatch(eis, [n] * G, follow)
         direct.append((cb, cb.event_graph(edge_weight=w)))
+    if not prefetch:   # an unfinished graph says so instead of failing somewhere inside a step
+        from causal_eeg_vae_amd import _lib
+        unfinished = direct[0][0].event_graph(defer=True)
+        with pytest.raises(_lib.CeegError, match="finish"):
+            unfinished.gcn_val
+        assert CollatedBatch.finish_graph(unfinished).gcn_val.shape == direct[0][1].gcn_val.shape
     got = list(MinibatchStream(items, prefetch=prefetch, depth=depth))
     torch.cuda.synchronize()
     assert len(got) == len(direct)
