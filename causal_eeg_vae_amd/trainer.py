@@ -34,8 +34,8 @@ def allreduce_grads_(params, world_size, force=False):
     else:
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)  # RCCL: in place on the device, stream-ordered
     flat.div_(world_size)
-    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    # back into the parameters' gradients with one multi-tensor copy (one launch instead of one per parameter)
+    torch._foreach_copy_(grads, list(torch._utils._unflatten_dense_tensors(flat, grads)))
 
 
 def broadcast_params_(module, src=0):
