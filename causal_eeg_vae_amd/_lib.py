@@ -25,6 +25,7 @@ SIGNATURES = {
     "ceeg_vq_forward": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_vq_forward_static_max_bytes": (_c_sz, []),
     "ceeg_vq_forward_static_prepare": (_c_int, []),
+    "ceeg_vq_forward_screened": (_c_int, [_vp, _c_sz, _c_i64, _c_int, _c_int, _c_int, _vp, _vp]),
     "ceeg_vq_forward_static": (_c_int, [_vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ceeg_vq_backward_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
     "ceeg_vq_backward": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _c_sz, _vp]),

@@ -124,7 +124,8 @@ template <int DP, bool EXACT>
 __global__ __launch_bounds__(VQ_THREADS, (EXACT && DP <= 128) ? 3 : 2) void vq_main_f32(
     const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ ee,
     const float* __restrict__ img, int64_t B, int n_e, int D, int n_ep,
-    float* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part) {
+    float* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part, const int* __restrict__ run_flag) {
+  if (run_flag && *run_flag == 0) return;  // behind vq_screen_f32: only if that kernel raised its flag (uniform: no barrier is skipped)
   constexpr int RT = 2;                 // 16-row tiles per wave
   constexpr int ROWS_W = RT * 16;       // rows per wave
   constexpr int BM = VQ_WAVES * ROWS_W; // rows per block
@@ -867,6 +868,292 @@ __global__ __launch_bounds__(VQ_BS_WAVES * 64, 1) void vq_main_bf16_bs(
   }
 }
 
+// ------------------------------------------------------------------------------------------ fp32 forward by screening
+// The fp32 quantiser's codes, bit for bit, at a fraction of the fp32 matrix time: bf16 MFMA scores of ALL codes with a rigorous
+// error bound pick a few candidates per row, and only those get the arithmetic the contract specifies (zz, ee, dot as k-ascending
+// fmaf chains, d = fl(fl(zz + ee) - 2 dot), lowest code on ties).
+//   s~_c = bf16(z) . bf16(w_c) - ee_c / 2    (v_mfma_f32_16x16x32_bf16, fp32 accumulation, ee_c = the contract's fp32 chain)
+//   sigma_c = (zz - d_c) / 2                 (what the contract maximises)
+//   |s~_c - sigma_c| <= Delta_row = c1 |z| max_c |w_c| + c2 (|z| + max_c |w_c|)^2 + c3 max_c |w_c|^2 + tiny
+//       c1: both operand roundings (2^-9 each, RNE) + the MFMA's product truncation and accumulator rounding + the fp32 chain's own
+//           rounding error, all relative to sum_k |z_k w_ck| <= |z| |w_c|;  c2: the two fl() of d;  c3: the accumulator's roundings
+//           on the -ee/2 it is seeded with.
+//   => the contract's winner c* (and every code tying with it) satisfies  s~_c* >= max_c s~_c - 2 Delta_row.
+// Pass 1 finds the row maxima, pass 2 recomputes the same scores (same instructions, same bits) and lists the codes above the
+// threshold; a lane then runs the chains of one (row, code) pair.  Whatever the bound cannot handle - more candidates than the
+// list holds (near-tie codebooks), a row without a finite maximum (NaN / inf input) - raises a device flag, and the full fp32
+// kernel, launched behind this one, runs only if the flag is up (it then rewrites every output): no host decision, and the result
+// never depends on how tight the bound is, only the time does.
+// One 1024-thread workgroup per CU keeps the whole bf16 codebook in LDS (n_ep * DP * 2 bytes <= 128 KB); a wave owns 32 rows at a time
+// (every phase of a unit is a latency chain - operand reads, the pairs' fmaf chains, the output gather - so the CU wants all 16 waves).
+constexpr int VQ_SC_WAVES = 16;
+constexpr int VQ_SC_RT = 2;                      // 16-row tiles per wave and unit
+constexpr int VQ_SC_ROWS = 16 * VQ_SC_RT;        // rows per unit
+constexpr int VQ_SC_LIST = 192;                  // candidate entries per wave and unit (expected on spread-out data: ~1.5 per row)
+
+// two fp32 -> packed bf16 with the hardware's round-to-nearest-even conversion (v_cvt_pk_bf16_f32); the screening bound needs
+// nothing of it but |relative error| <= 2^-9
+typedef __bf16 vq_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float vq_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned vq_pack_bf16(float lo, float hi) {
+  const vq_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, vq_bf16x2));
+}
+
+template <int DP>
+__global__ __launch_bounds__(VQ_SC_WAVES * 64, 1) void vq_screen_f32(
+    const float* __restrict__ z, const float* __restrict__ W, const float* __restrict__ ee, const unsigned short* __restrict__ img16,
+    int64_t B, int n_e, int n_ep, float* __restrict__ z_q, int64_t* __restrict__ idx_out, float* __restrict__ err_part,
+    int* __restrict__ flag) {
+  constexpr int KS = DP / 32;                    // MFMA k-steps
+  constexpr int CPR = DP / 8;                    // 16-byte pieces per bf16 row
+  constexpr int SWZ_MASK = vq_min(16, CPR) - 1;
+  constexpr int RT = VQ_SC_RT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* lds_img = smem;                                                          // [n_ep][DP] bf16, pieces XOR-swizzled per row
+  float* lds_bias = reinterpret_cast<float*>(smem + (size_t)n_ep * DP * 2);      // [n_ep]  -ee/2 (padded codes: -inf)
+  unsigned* lds_list = reinterpret_cast<unsigned*>(lds_bias + n_ep);             // [WAVES][LIST]  (row in unit) << 16 | code
+  unsigned long long* lds_key = reinterpret_cast<unsigned long long*>(lds_list + VQ_SC_WAVES * VQ_SC_LIST);  // [WAVES][ROWS] (ordered d, code)
+  int* lds_cnt = reinterpret_cast<int*>(lds_key + VQ_SC_WAVES * VQ_SC_ROWS);      // [WAVES][ROWS]  listed codes per row
+  int* lds_total = lds_cnt + VQ_SC_WAVES * VQ_SC_ROWS;                            // [WAVES]  entries in the wave's list
+  float* lds_red = reinterpret_cast<float*>(lds_total + VQ_SC_WAVES);             // [WAVES + 1]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 15, q = lane >> 4;
+
+  // ---- codebook image and biases -> LDS (once per workgroup); max_c |w_c| for the bound
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(img16);
+    uint4* dst = reinterpret_cast<uint4*>(lds_img);
+    const int pieces = n_ep * CPR;
+    for (int i = tid; i < pieces; i += VQ_SC_WAVES * 64) dst[i] = src[i];
+    float wm = 0.f;
+    for (int c = tid; c < n_ep; c += VQ_SC_WAVES * 64) {
+      const float e = c < n_e ? ee[c] : INFINITY;
+      lds_bias[c] = -0.5f * e;
+      if (c < n_e) wm = fmaxf(wm, e);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+    if (lane == 0) lds_red[wave] = wm;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+      for (int w = 0; w < VQ_SC_WAVES; ++w) t = fmaxf(t, lds_red[w]);
+      lds_red[VQ_SC_WAVES] = t;
+    }
+    __syncthreads();
+  }
+  const float wmax = sqrtf(lds_red[VQ_SC_WAVES]) * 1.0001f;   // >= max_c |w_c| (ee is the fp32 chain of |w_c|^2: relative error << 1e-4)
+  const bool wfinite = wmax < INFINITY;                      // NaN / inf codebook: the full kernel decides (flag below)
+
+  unsigned* my_list = lds_list + wave * VQ_SC_LIST;
+  unsigned long long* my_key = lds_key + wave * VQ_SC_ROWS;
+  int* my_cnt = lds_cnt + wave * VQ_SC_ROWS;
+  int* my_total = lds_total + wave;
+  const int nct = n_ep / 16;
+  float err = 0.f;
+  bool raise = !wfinite;
+
+  const int64_t nunits = (B + VQ_SC_ROWS - 1) / VQ_SC_ROWS;
+  const int64_t stride = (int64_t)gridDim.x * VQ_SC_WAVES;
+  for (int64_t unit = (int64_t)blockIdx.x * VQ_SC_WAVES + wave; unit < nunits; unit += stride) {
+    const int64_t row0 = unit * VQ_SC_ROWS;
+    // ---- z -> bf16 MFMA operands: lane (n, q) keeps z~[row n of tile rt][32 s + 8 q .. + 8]; |z|^2 per row for the bound
+    u16x8 zb[RT][KS];
+    float thr[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      int64_t row = row0 + rt * 16 + n;
+      row = row < B ? row : B - 1;
+      const float* zr = z + row * DP;
+      float n2 = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const float4 v0 = *reinterpret_cast<const float4*>(zr + 32 * s + 8 * q);
+        const float4 v1 = *reinterpret_cast<const float4*>(zr + 32 * s + 8 * q + 4);
+        n2 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w + v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+        const uint4 pk = make_uint4(vq_pack_bf16(v0.x, v0.y), vq_pack_bf16(v0.z, v0.w), vq_pack_bf16(v1.x, v1.y), vq_pack_bf16(v1.z, v1.w));
+        zb[rt][s] = __builtin_bit_cast(u16x8, pk);
+      }
+      n2 += __shfl_xor(n2, 16, 64);
+      n2 += __shfl_xor(n2, 32, 64);
+      const float zn = sqrtf(n2) * 1.0001f;                  // >= |z_row|
+      // Delta_row (see the header): c1 = 2^-8 * 1.05 (K <= 256); the two fl() of d cost 2^-24 (|z| + |w|)^2 (2^-22 taken), the
+      // accumulator's roundings on the -ee/2 it starts from (K/8) 2^-25 |w|^2 (2^-19 taken); an absolute grain covers flushed subnormals
+      const float sum = zn + wmax;
+      thr[rt] = 2.0f * (0.0041015625f * zn * wmax + 2.384185791015625e-7f * sum * sum + 1.9073486328125e-6f * wmax * wmax + 1e-30f);  // 2 Delta_row for now
+    }
+    // ---- pass 1: row maxima of the bf16 scores
+    float m[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) m[rt] = -INFINITY;
+    // two code tiles (ct, ct + 1) at once: 2 RT independent accumulator chains, all operand reads issued up front
+    auto scores = [&](int ct, f32x4 (&acc)[2][RT]) {
+      u16x8 a[2][KS];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int c = (ct + t) * 16 + n;                       // the A operand row this lane reads: code (ct + t)*16 + (lane & 15)
+        const char* wrow = lds_img + (size_t)c * DP * 2;
+        const int sw = c & SWZ_MASK;
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(lds_bias + (ct + t) * 16 + 4 * q);
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc[t][rt] = bias;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) a[t][s] = *reinterpret_cast<const u16x8*>(wrow + (((4 * s + q) ^ sw) << 4));
+      }
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+            acc[t][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a[t][s]), __builtin_bit_cast(bf16x8_t, zb[rt][s]),
+                                                                acc[t][rt], 0, 0, 0);
+    };
+    for (int ct = 0; ct < nct; ct += 2) {   // n_ep is a multiple of 32
+      f32x4 acc[2][RT];
+      scores(ct, acc);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          m[rt] = fmaxf(fmaxf(fmaxf(m[rt], acc[t][rt][0]), fmaxf(acc[t][rt][1], acc[t][rt][2])), acc[t][rt][3]);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      m[rt] = fmaxf(m[rt], __shfl_xor(m[rt], 16, 64));
+      m[rt] = fmaxf(m[rt], __shfl_xor(m[rt], 32, 64));
+      bad |= !(fabsf(m[rt]) < INFINITY) || !(thr[rt] < INFINITY);   // NaN / inf rows: no finite maximum or no finite bound
+      thr[rt] = m[rt] - thr[rt];
+    }
+    // ---- pass 2: the same scores again; every (row, code) at or above the row's threshold goes to the wave's list
+    if (lane < VQ_SC_ROWS) {
+      my_key[lane] = ~0ull;
+      my_cnt[lane] = 0;
+    }
+    if (lane == 0) *my_total = 0;
+    // The listing of tile pair p runs while the MFMAs of pair p + 1 are in flight (two accumulator sets): a data-dependent branch
+    // right behind its own MFMAs would drain the pipeline once per trip.
+    for (int ct = 0; ct < nct; ct += 2) {
+      f32x4 acc[2][RT];
+      scores(ct, acc);
+      bool hit = false;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+          hit |= fmaxf(fmaxf(acc[t][rt][0], acc[t][rt][1]), fmaxf(acc[t][rt][2], acc[t][rt][3])) >= thr[rt];
+      if (hit) {   // rare per lane: the slot comes from the wave's LDS counter (the order of the list does not matter: what is
+                   // taken from it - a count per row and an integer minimum per row - does not depend on it)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (acc[t][rt][i] >= thr[rt]) {
+                const int slot = atomicAdd(my_total, 1);
+                if (slot < VQ_SC_LIST) my_list[slot] = ((unsigned)(rt * 16 + n) << 16) | (unsigned)((ct + t) * 16 + 4 * q + i);
+              }
+      }
+    }
+    const int cnt = __builtin_amdgcn_readfirstlane(*my_total);
+    bad |= cnt > VQ_SC_LIST;
+    if (__any(bad)) {   // this unit's rows are left to the full kernel (it rewrites every output once the flag is up)
+      raise = true;
+      continue;
+    }
+    // ---- a row with ONE listed code is decided (the winner is in the list); the others get the contract's arithmetic, a lane per pair
+    for (int b0 = 0; b0 < cnt; b0 += 64)
+      if (b0 + lane < cnt) atomicAdd(&my_cnt[my_list[b0 + lane] >> 16], 1);
+    for (int b0 = 0; b0 < cnt; b0 += 64) {
+      const int e = b0 + lane;
+      if (e < cnt && my_cnt[my_list[e] >> 16] == 1) {
+        const unsigned ent = my_list[e];
+        my_key[ent >> 16] = (unsigned long long)(ent & 0xffffu);
+      } else if (e < cnt) {
+        const unsigned ent = my_list[e];
+        const int code = (int)(ent & 0xffffu);
+        int64_t row = row0 + (int)(ent >> 16);
+        row = row < B ? row : B - 1;
+        const float* zr = z + row * DP;
+        const float* wr = W + (size_t)code * DP;
+        float zz = 0.f, dot = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < DP; k += 4) {
+          const float4 a = *reinterpret_cast<const float4*>(zr + k);
+          const float4 w = *reinterpret_cast<const float4*>(wr + k);
+          zz = __fmaf_rn(a.x, a.x, zz); zz = __fmaf_rn(a.y, a.y, zz); zz = __fmaf_rn(a.z, a.z, zz); zz = __fmaf_rn(a.w, a.w, zz);
+          dot = __fmaf_rn(a.x, w.x, dot); dot = __fmaf_rn(a.y, w.y, dot); dot = __fmaf_rn(a.z, w.z, dot); dot = __fmaf_rn(a.w, w.w, dot);
+        }
+        const float d = __fmaf_rn(-2.0f, dot, zz + ee[code]);  // fl(fl(zz + ee) - 2 dot), as vq_main_f32
+        if (d == d) {   // a NaN never wins (vq_main_f32's strict <)
+          // lowest d, lowest code on ties = the minimum of (d mapped to an order-preserving integer, code); an integer minimum
+          // does not depend on the order of the updates
+          const unsigned u = __float_as_uint(d);
+          const unsigned ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+          atomicMin(&my_key[ent >> 16], ((unsigned long long)ord << 32) | (unsigned long long)code);
+        }
+      }
+    }
+    // (same wave wrote the keys: LDS operations of a wave complete in order)
+    {
+      const unsigned long long got = lane < VQ_SC_ROWS ? my_key[lane] : 0ull;
+      if (__any(got == ~0ull && row0 + lane < B)) {   // a row whose every listed d is NaN: the full kernel's rule applies
+        raise = true;
+        continue;
+      }
+      if (lane < VQ_SC_ROWS && row0 + lane < B) idx_out[row0 + lane] = (int64_t)(got & 0xffffffffull);
+    }
+    // ---- z_q rows (the codebook rows), squared error: lane-consecutive 16-byte pieces of the unit's contiguous block
+    constexpr int PPR = DP / 4;
+    constexpr int NP = VQ_SC_ROWS * PPR / 64;
+#pragma unroll 4
+    for (int j = 0; j < NP; ++j) {
+      const int p = j * 64 + lane;
+      const int lr = p / PPR, c4 = 4 * (p % PPR);
+      const int64_t row = row0 + lr;
+      if (row < B) {
+        const int id = (int)(my_key[lr] & 0xffffffffull);
+        const float4 wv = *reinterpret_cast<const float4*>(W + (size_t)id * DP + c4);
+        const float4 zv = *reinterpret_cast<const float4*>(z + row * DP + c4);
+        *reinterpret_cast<float4*>(z_q + row * DP + c4) = wv;
+        const float dx = wv.x - zv.x, dy = wv.y - zv.y, dz = wv.z - zv.z, dw = wv.w - zv.w;
+        err = __fmaf_rn(dx, dx, err);
+        err = __fmaf_rn(dy, dy, err);
+        err = __fmaf_rn(dz, dz, err);
+        err = __fmaf_rn(dw, dw, err);
+      }
+    }
+  }
+  if (__any(raise) && lane == 0) atomicOr(flag, 1);   // integer OR: order-independent
+  err = ceeg_wave_sum(err);
+  __syncthreads();
+  if (lane == 0) lds_red[wave] = err;
+  __syncthreads();
+  if (tid == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < VQ_SC_WAVES; ++w) t += lds_red[w];
+    err_part[blockIdx.x] = t;
+  }
+}
+
+// bf16 codebook rows for vq_screen_f32: [n_ep][DP], 16-byte pieces XOR-swizzled inside a row (piece p of row c at p ^ (c & mask));
+// rows >= n_e and columns >= D are zero
+__global__ void vq_screen_prep_kernel(const float* __restrict__ W, int n_e, int D, int n_ep, int DP, unsigned short* __restrict__ img16) {
+  const int64_t total = (int64_t)n_ep * DP;
+  const int cpr = DP / 8;
+  const int mask = vq_min(16, cpr) - 1;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i / DP), k = (int)(i % DP);
+    const float w = (c < n_e && k < D) ? W[(size_t)c * D + k] : 0.f;
+    img16[(size_t)c * DP + ((((k >> 3) ^ (c & mask)) << 3) | (k & 7))] = ceeg_f32_to_bf16(w);
+  }
+}
+
 // ------------------------------------------------------------------------------------------ histogram
 // slice g covers rows [g*rows_per, (g+1)*rows_per); counts in LDS (integer adds commute: deterministic)
 __global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int64_t rows_per,
@@ -890,7 +1177,12 @@ __global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n
 __global__ __launch_bounds__(1024) void vq_finalize_kernel(const float* __restrict__ err_part, int nblk,
                                                            const uint32_t* __restrict__ hpart, int nslice, int n_e, int64_t B,
                                                            int D, float beta, float* __restrict__ loss, float* __restrict__ ppl,
-                                                           uint32_t* __restrict__ hist) {
+                                                           uint32_t* __restrict__ hist, const float* __restrict__ err_alt, int nblk_alt,
+                                                           const int* __restrict__ alt_flag) {
+  if (alt_flag && *alt_flag != 0) {  // the screening kernel handed over to the full kernel: its partial sums count
+    err_part = err_alt;
+    nblk = nblk_alt;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
   __shared__ double red[1024];
@@ -1124,7 +1416,16 @@ struct VqFwdWs {
   void* img;
   float* err_part;
   uint32_t* hpart;
+  unsigned short* img16 = nullptr;  // fp32 forward by screening (vq_screen_f32): bf16 codebook rows, its partial sums, its flag
+  float* err_sc = nullptr;
+  int* flag = nullptr;
 };
+// shapes vq_screen_f32 takes: fp32, D a power of two >= 32 (= DP), the bf16 codebook within 128 KB of LDS
+bool vq_screen_shape(int n_e, int D, int dtype) {
+  if (dtype != CEEG_F32 || D < 32 || (D & (D - 1)) != 0 || D > 256) return false;
+  const int n_ep = (n_e + 31) / 32 * 32;
+  return (size_t)n_ep * D * 2 <= (size_t)128 * 1024 && n_e < 65536;
+}
 size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_bytes, VqFwdWs* out) {
   const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
   const int n_ep = (n_e + CT - 1) / CT * CT;
@@ -1132,19 +1433,52 @@ size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_b
   CeegWs a(ws, ws_bytes);
   size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4, 1) +
                 ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)vq_nslice(B) * n_e, 4);
+  const bool sc = vq_screen_shape(n_e, D, dtype);
+  if (sc) need += ceeg_ws_part((size_t)n_ep * DP, 2) + ceeg_ws_part(256, 4) + ceeg_ws_part(1, 4);
   if (out) {
     out->ee = a.take<float>(n_ep);
     out->img = a.take<char>((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4);
     out->err_part = a.take<float>(nblk);
     out->hpart = a.take<uint32_t>((size_t)vq_nslice(B) * n_e);
+    if (sc) {
+      out->img16 = a.take<unsigned short>((size_t)n_ep * DP);
+      out->err_sc = a.take<float>(256);
+      out->flag = a.take<int>(1);
+    }
     if (!a.ok) return 0;
   }
   return need;
 }
 
+bool vq_screen_on() {  // read per call: CEEG_VQ_SCREEN=0 keeps the full fp32 kernel alone (the checker of the screened form)
+  const char* e = getenv("CEEG_VQ_SCREEN");
+  return !(e && e[0] == '0');
+}
+// returns the number of workgroups (= partial sums) of the screening launch, 0 when the shape is not taken
+template <int DP>
+int launch_screen(const float* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, float* z_q, int64_t* idx,
+                  hipStream_t st) {
+  if constexpr (DP < 32) {
+    return 0;
+  } else {
+    if (D != DP || !w.img16 || !vq_screen_on()) return 0;
+    const int64_t nunits = (B + VQ_SC_ROWS - 1) / VQ_SC_ROWS;
+    const int64_t want = (nunits + VQ_SC_WAVES - 1) / VQ_SC_WAVES;
+    const int grid = (int)(want < 256 ? want : 256);   // one persistent workgroup per CU
+    const size_t lds = (size_t)n_ep * DP * 2 + (size_t)n_ep * 4 + (size_t)VQ_SC_WAVES * VQ_SC_LIST * 4 + (size_t)VQ_SC_WAVES * VQ_SC_ROWS * 12 +
+                       (2 * VQ_SC_WAVES + 1) * 4;
+    const int64_t total = (int64_t)n_ep * DP;
+    if (hipMemsetAsync(w.flag, 0, sizeof(int), st) != hipSuccess) return -1;
+    hipLaunchKernelGGL(vq_screen_prep_kernel, dim3((unsigned)((total + 255) / 256 < 512 ? (total + 255) / 256 : 512)), dim3(256), 0, st, W, n_e, D,
+                       n_ep, DP, w.img16);
+    hipLaunchKernelGGL((vq_screen_f32<DP>), dim3((unsigned)grid), dim3(VQ_SC_WAVES * 64), lds, st, z, W, w.ee, w.img16, B, n_e, n_ep, z_q, idx,
+                       w.err_sc, w.flag);
+    return grid;
+  }
+}
 template <int DP>
 void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int n_e, int D, int n_ep, float* z_q,
-                int64_t* idx, int64_t nblk, hipStream_t st) {
+                int64_t* idx, int64_t nblk, hipStream_t st, const int* run_flag) {
   size_t lds = 2 * (32 * DP * 4 + 32 * 4) + 128 * 4 + 16;
   if (D == DP && DP <= 128) {  // per-wave z strips (VIA_LDS) overlay everything after chunk buffer 0
     const size_t with_strips = (32 * DP * 4 + 32 * 4) + (size_t)VQ_WAVES * 16 * (DP + 4) * 4;
@@ -1152,10 +1486,10 @@ void launch_f32(const float* z, const float* W, const VqFwdWs& w, int64_t B, int
   }
   if (D == DP)
     hipLaunchKernelGGL((vq_main_f32<DP, true>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
-                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
+                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part, run_flag);
   else
     hipLaunchKernelGGL((vq_main_f32<DP, false>), dim3((unsigned)nblk), dim3(VQ_THREADS), lds, st, z, W, w.ee,
-                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part);
+                       reinterpret_cast<const float*>(w.img), B, n_e, D, n_ep, z_q, idx, w.err_part, run_flag);
 }
 bool vq_bs_off() {  // checker's switch (read per call): CEEG_VQ_BF16_BS=0 selects the row-stationary kernel
   const char* e = getenv("CEEG_VQ_BF16_BS");
@@ -1218,6 +1552,7 @@ int vq_forward_run(const void* z, const float* W, int64_t B, int n_e, int D, int
   const int DP = vq_dp(D, dtype), CT = vq_ct(dtype);
   const int n_ep = (n_e + CT - 1) / CT * CT;
   int64_t nblk = (B + vq_bm(dtype) - 1) / vq_bm(dtype);
+  int n_sc = 0;  // partial sums of the screening launch (fp32 only)
 
   const int prep_blocks = (int)(((int64_t)n_ep * DP + 255) / 256 < 1024 ? ((int64_t)n_ep * DP + 255) / 256 : 1024);
   if (dtype == CEEG_BF16)
@@ -1229,14 +1564,22 @@ int vq_forward_run(const void* z, const float* W, int64_t B, int n_e, int D, int
   if (dtype == CEEG_F32) {
     const float* zf = static_cast<const float*>(z);
     float* zq = static_cast<float*>(z_q);
+    // screened form first where the shape allows (vq_screen_f32); the full kernel behind it then runs only if the flag went up
+#define VQ_F32_CASE(P)                                                                                                  \
+  case P:                                                                                                               \
+    n_sc = launch_screen<P>(zf, W, w, B, n_e, D, n_ep, zq, idx, st);                                                    \
+    if (n_sc < 0) return CEEG_ELAUNCH;                                                                                  \
+    launch_f32<P>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st, n_sc > 0 ? w.flag : nullptr);                            \
+    break;
     switch (DP) {
-      case 16: launch_f32<16>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
-      case 32: launch_f32<32>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
-      case 64: launch_f32<64>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
-      case 128: launch_f32<128>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
-      case 256: launch_f32<256>(zf, W, w, B, n_e, D, n_ep, zq, idx, nblk, st); break;
+      VQ_F32_CASE(16)
+      VQ_F32_CASE(32)
+      VQ_F32_CASE(64)
+      VQ_F32_CASE(128)
+      VQ_F32_CASE(256)
       default: return CEEG_EUNSUPPORTED;
     }
+#undef VQ_F32_CASE
   } else {
     switch (DP) {
       case 32: nblk = launch_bf16<32>(z, W, w, B, n_e, D, n_ep, z_q, idx, nblk, st); break;
@@ -1254,8 +1597,12 @@ int vq_forward_run(const void* z, const float* W, int64_t B, int n_e, int D, int
   const int nslice = (int)((B + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, rows_per, w.hpart);
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(1024), (size_t)n_e * 4, st, w.err_part, (int)nblk, w.hpart, nslice, n_e, B, D, beta,
-                     loss, perplexity, hist);
+  if (n_sc > 0)  // the screening kernel's sums, unless its flag says the full kernel took over
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(1024), (size_t)n_e * 4, st, w.err_sc, n_sc, w.hpart, nslice, n_e, B, D, beta, loss,
+                       perplexity, hist, w.err_part, (int)nblk, w.flag);
+  else
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(1024), (size_t)n_e * 4, st, w.err_part, (int)nblk, w.hpart, nslice, n_e, B, D, beta,
+                       loss, perplexity, hist, static_cast<const float*>(nullptr), 0, static_cast<const int*>(nullptr));
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
@@ -1270,6 +1617,22 @@ extern "C" int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e
   if (ws_bytes < vq_fwd_layout(B, n_e, D, dtype, nullptr, 0, nullptr)) return CEEG_EWORKSPACE;
   if (!ws || !ceeg_aligned(ws, 256) || vq_fwd_layout(B, n_e, D, dtype, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
   return vq_forward_run(z, W, B, n_e, D, dtype, beta, z_q, idx, loss, perplexity, hist, w, static_cast<hipStream_t>(stream));
+}
+
+// Test / measurement helper: did the screened form (vq_screen_f32) decide the last fp32 forward that used this workspace, or did it
+// hand over to the full kernel?  *out = 1 screened, 0 handed over, -1 the shape (or CEEG_VQ_SCREEN=0) does not screen.  Synchronises.
+extern "C" int ceeg_vq_forward_screened(const void* ws, size_t ws_bytes, int64_t B, int n_e, int D, int dtype, int* out, void* stream) {
+  if (!ws || !out || B <= 0 || n_e <= 0 || D <= 0 || D > 256) return CEEG_EINVAL;
+  *out = -1;
+  if (!vq_screen_shape(n_e, D, dtype) || D != vq_dp(D, dtype) || !vq_screen_on()) return CEEG_OK;
+  VqFwdWs w;
+  if (vq_fwd_layout(B, n_e, D, dtype, const_cast<void*>(ws), ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  int flag = 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemcpyAsync(&flag, w.flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+    return CEEG_ELAUNCH;
+  *out = flag ? 0 : 1;
+  return CEEG_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- forward without a workspace

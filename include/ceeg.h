@@ -90,6 +90,13 @@ int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, in
  * Set-up: the array's device address is looked up (hipGetSymbolAddress, under a mutex) on the FIRST call on each device; that
  * lookup may load the code object and is not capture-safe.  Call ceeg_vq_forward_static_prepare() once per device, with that device
  * current, outside any stream capture (or make the first ceeg_vq_forward_static call there); calls after it only launch kernels. */
+/* fp32 forwards whose bf16 codebook fits 128 KB of LDS (n_e * D * 2 bytes, D a power of two >= 32) run in a SCREENED form: bf16 MFMA
+ * scores of all codes with a rigorous error bound pick the few codes that can win a row, and only those get the arithmetic above -
+ * same codes, same z_q, bit for bit (csrc/vq.hip, vq_screen_f32); whatever the bound cannot decide (near-tie codebooks, NaN / inf)
+ * falls to the full kernel on the device, without a host decision.  CEEG_VQ_SCREEN=0 keeps the full kernel alone.  This helper (no
+ * counterpart in the reference; tests and measurements) reports which of the two decided the last forward on workspace `ws`:
+ * *out = 1 screened, 0 full kernel, -1 the call does not screen.  It synchronises the stream. */
+int ceeg_vq_forward_screened(const void* ws, size_t ws_bytes, int64_t B, int n_e, int D, int dtype, int* out, void* stream);
 int ceeg_vq_forward_static_prepare(void);
 size_t ceeg_vq_forward_static_max_bytes(void);
 int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, int n_e, int D, int dtype, float beta,

@@ -223,3 +223,104 @@ def test_errors_are_loud():
         vq(torch.randn(4, 300, device="cuda"))  # e_dim > 256 unsupported
     with pytest.raises(ValueError):
         VectorQuantizer(16, 8, 0.25).cuda()(torch.randn(4, 9, device="cuda"))
+
+
+def _fwd_f32_abi(z, W, beta=0.25):
+    """ceeg_vq_forward (fp32) through the C-ABI; returns (idx, z_q, loss, screened) with screened = 1 / 0 / -1 as
+    ceeg_vq_forward_screened reports it."""
+    import ctypes
+    from causal_eeg_vae_amd import _lib
+    L = _lib.lib()
+    B, D = z.shape
+    n_e = W.shape[0]
+    zq = torch.empty_like(z)
+    idx = torch.empty(B, dtype=torch.int64, device="cuda")
+    sc = torch.empty(2, device="cuda")
+    ws = _lib.workspace(L.ceeg_vq_forward_ws_bytes(B, n_e, D, _lib.CEEG_F32), z.device)
+    _lib.check(L.ceeg_vq_forward(z.data_ptr(), W.data_ptr(), B, n_e, D, _lib.CEEG_F32, beta, zq.data_ptr(), idx.data_ptr(), sc[0:].data_ptr(),
+                                 sc[1:].data_ptr(), None, ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_vq_forward")
+    how = ctypes.c_int(-7)
+    _lib.check(L.ceeg_vq_forward_screened(ws.data_ptr(), ws.numel(), B, n_e, D, _lib.CEEG_F32, ctypes.addressof(how), _lib.stream()),
+               "ceeg_vq_forward_screened")
+    return idx, zq, float(sc[0]), how.value
+
+
+def _screen_case(kind, B, n_e, D, rng):
+    z = rng.standard_normal((B, D)).astype(np.float32)
+    W = rng.standard_normal((n_e, D)).astype(np.float32)
+    if kind == "small_codebook":
+        W *= 0.1
+    elif kind == "ref_init":                      # the reference's U(+-1/n_e) initialisation
+        W = rng.uniform(-1.0 / n_e, 1.0 / n_e, (n_e, D)).astype(np.float32)
+    elif kind == "all_near":                      # one code plus noise in the last bits: every code is a candidate of every row
+        W = (W[:1] * (1 + 2e-7 * rng.standard_normal((n_e, D)))).astype(np.float32)
+    elif kind == "duplicates":                    # exact ties between code pairs: the lower index must win
+        W[n_e // 2:] = W[: n_e - n_e // 2]
+    elif kind == "near_duplicates":               # ties broken in the last bits of the fp32 chain
+        W[1::2] = W[0::2][: W[1::2].shape[0]] * (1 + 3e-7 * rng.standard_normal((W[1::2].shape[0], 1)).astype(np.float32))
+    elif kind == "rows_on_codes":                 # z almost equal to a code: distances cancel to ~0
+        z = (W[rng.integers(0, n_e, B)] * (1 + 1e-6 * rng.standard_normal((B, D)))).astype(np.float32)
+    elif kind == "wide_range":                    # a few huge components per row and per code
+        z[:, ::17] *= 3e3
+        W[:, 5::29] *= 1e3
+    elif kind == "tiny":
+        z *= 1e-19
+        W *= 1e-19
+    elif kind == "huge":
+        z *= 1e15
+        W *= 1e3
+    elif kind == "mixed_rows":                    # row scales from 1e-6 to 1e6 in one batch
+        z *= (10.0 ** rng.uniform(-6, 6, (B, 1))).astype(np.float32)
+    elif kind == "zero_rows":
+        z[::3] = 0
+        W[7] = 0
+    return z, W
+
+
+@pytest.mark.parametrize("kind", ["normal", "small_codebook", "ref_init", "all_near", "duplicates", "near_duplicates", "rows_on_codes", "wide_range", "tiny",
+                                  "huge", "mixed_rows", "zero_rows"])
+@pytest.mark.parametrize("B,n_e,D", [(3001, 512, 128), (4100, 100, 32), (1500, 256, 256), (33, 64, 64), (1, 512, 128)])
+def test_fp32_screened_forward_bit_exact(kind, B, n_e, D, monkeypatch):
+    """The screened fp32 forward (bf16 MFMA scores + error bound -> candidates -> the contract's fmaf chains; csrc/vq.hip
+    vq_screen_f32) against the C oracle and against the full kernel (CEEG_VQ_SCREEN=0): codes and z_q bit for bit on spread-out
+    data, exact and near ties, rows sitting on codes, extreme and mixed scales - whichever of the two forms ends up deciding."""
+    from oracle import c_oracle
+    rng = np.random.default_rng(sum(map(ord, kind)) * 1000003 + B * 131 + n_e * 7 + D)
+    zn, Wn = _screen_case(kind, B, n_e, D, rng)
+    z, W = torch.from_numpy(zn).cuda(), torch.from_numpy(Wn).cuda()
+    idx, zq, loss, how = _fwd_f32_abi(z, W)
+    assert how in (0, 1)
+    if kind in ("normal", "small_codebook", "ref_init") and n_e * D >= 64 * 64:
+        assert how == 1                            # spread-out data must not need the full kernel
+    if kind == "all_near" and n_e >= 256 and B >= 33:
+        assert how == 0                            # more candidates than the list holds: handed over on the device
+    o = c_oracle.vq_forward_f32(zn, Wn, 0.25)
+    np.testing.assert_array_equal(idx.cpu().numpy(), o["idx"])
+    np.testing.assert_array_equal(zq.cpu().numpy(), o["z_q"])
+    monkeypatch.setenv("CEEG_VQ_SCREEN", "0")
+    idx0, zq0, loss0, how0 = _fwd_f32_abi(z, W)
+    assert how0 == -1 and torch.equal(idx, idx0) and torch.equal(zq, zq0)
+    np.testing.assert_allclose(loss, loss0, rtol=1e-5, atol=1e-30)
+
+
+def test_fp32_screened_forward_non_finite_rows(monkeypatch):
+    """NaN / inf in z: the screening kernel raises its flag and the full kernel's rules decide; a NaN code is never a candidate, as
+    it never wins the full kernel's strict comparison - outputs equal the unscreened call's on every row."""
+    rng = np.random.default_rng(11)
+    B, n_e, D = 2000, 512, 128
+    z = torch.from_numpy(rng.standard_normal((B, D)).astype(np.float32)).cuda()
+    W = torch.from_numpy(rng.standard_normal((n_e, D)).astype(np.float32)).cuda()
+    for case in ("nan_row", "inf_row", "nan_code"):
+        zz, WW = z.clone(), W.clone()
+        if case == "nan_row":
+            zz[5, 3] = float("nan"); zz[1999] = float("nan")
+        elif case == "inf_row":
+            zz[17, 100] = float("inf"); zz[18, 0] = -float("inf")
+        else:
+            WW[44, 7] = float("nan")
+        monkeypatch.setenv("CEEG_VQ_SCREEN", "1")
+        idx, zq, _, how = _fwd_f32_abi(zz, WW)
+        assert how == (1 if case == "nan_code" else 0)   # a NaN code never wins in either form; a NaN / inf row has no finite maximum
+        monkeypatch.setenv("CEEG_VQ_SCREEN", "0")
+        idx0, zq0, _, _ = _fwd_f32_abi(zz, WW)
+        assert torch.equal(idx, idx0) and torch.equal(zq.view(torch.int32), zq0.view(torch.int32))
