@@ -959,6 +959,8 @@ __global__ __launch_bounds__(VQ_SC_WAVES * 64, 1) void vq_screen_f32(
   const int64_t stride = (int64_t)gridDim.x * VQ_SC_WAVES;
   for (int64_t unit = (int64_t)blockIdx.x * VQ_SC_WAVES + wave; unit < nunits; unit += stride) {
     const int64_t row0 = unit * VQ_SC_ROWS;
+    // somebody already handed the call over to the full kernel (it rewrites every output): no point in finishing the screening
+    if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
     // ---- z -> bf16 MFMA operands: lane (n, q) keeps z~[row n of tile rt][32 s + 8 q .. + 8]; |z|^2 per row for the bound
     u16x8 zb[RT][KS];
     float thr[RT];
@@ -1036,6 +1038,7 @@ __global__ __launch_bounds__(VQ_SC_WAVES * 64, 1) void vq_screen_f32(
     if (lane == 0) *my_total = 0;
     // The listing of tile pair p runs while the MFMAs of pair p + 1 are in flight (two accumulator sets): a data-dependent branch
     // right behind its own MFMAs would drain the pipeline once per trip.
+    bool over = false;
     for (int ct = 0; ct < nct; ct += 2) {
       f32x4 acc[2][RT];
       scores(ct, acc);
@@ -1056,13 +1059,16 @@ __global__ __launch_bounds__(VQ_SC_WAVES * 64, 1) void vq_screen_f32(
               if (acc[t][rt][i] >= thr[rt]) {
                 const int slot = atomicAdd(my_total, 1);
                 if (slot < VQ_SC_LIST) my_list[slot] = ((unsigned)(rt * 16 + n) << 16) | (unsigned)((ct + t) * 16 + 4 * q + i);
+                over |= slot >= VQ_SC_LIST;
               }
       }
+      if (__any(over)) break;   // the list is full: the unit is handed over below (cnt > VQ_SC_LIST), no point in listing on
     }
     const int cnt = __builtin_amdgcn_readfirstlane(*my_total);
     bad |= cnt > VQ_SC_LIST;
     if (__any(bad)) {   // this unit's rows are left to the full kernel (it rewrites every output once the flag is up)
       raise = true;
+      if (lane == 0) atomicOr(flag, 1);   // at once, so that the other waves stop early (integer OR: order-independent)
       continue;
     }
     // ---- a row with ONE listed code is decided (the winner is in the list); the others get the contract's arithmetic, a lane per pair
