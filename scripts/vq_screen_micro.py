@@ -33,4 +33,5 @@ for _ in range(10):
     run()
 e.record()
 torch.cuda.synchronize()
-print(f"SCREEN={os.environ.get('CEEG_VQ_SCREEN', '1')} DBG={os.environ.get('CEEG_VQ_DBG', '0')}: {s.elapsed_time(e) / 10:.3f} ms  idxsum {int(idx.sum())} loss {float(sc[0]):.6f}")
+print(f"CEEG_VQ_SCREEN={os.environ.get('CEEG_VQ_SCREEN', '1')}: {s.elapsed_time(e) / 10:.3f} ms per forward (prep + main + histogram + finalize)  "
+      f"idxsum {int(idx.sum())} loss {float(sc[0]):.6f}")
