@@ -29,7 +29,8 @@ namespace {
 
 constexpr int VQ_WAVES = 4;        // waves per block
 constexpr int VQ_THREADS = VQ_WAVES * 64;
-constexpr int VQ_HIST_ROWS = 4096; // rows per histogram slice
+constexpr int VQ_HIST_ROWS = 1024; // rows per histogram slice (one wave of the stable scatter walks a slice)
+constexpr int VQ_FWD_SLICES = 128; // histogram slices of the forward (the backward's stable scatter takes VQ_HIST_ROWS rows per slice)
 constexpr int VQ_SEG = 256;        // sorted rows per backward chunk
 
 __host__ __device__ constexpr int vq_min(int a, int b) { return a < b ? a : b; }
@@ -50,7 +51,23 @@ __global__ void vq_prep_kernel(const float* __restrict__ W, int n_e, int D, int 
     float e;
     if (c < n_e) {
       e = 0.f;
-      for (int k = 0; k < D; ++k) {
+      int k = 0;
+      for (; k + 32 <= D && (D & 3) == 0; k += 32) {  // 8 x 16 bytes in flight; the chain stays k-ascending (W is 16-byte aligned)
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(W + (size_t)c * D + k + 4 * u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          float w4[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            float w = w4[t];
+            if (BF16) w = ceeg_bf16_to_f32(ceeg_f32_to_bf16(w));
+            e = __fmaf_rn(w, w, e);
+          }
+        }
+      }
+      for (; k < D; ++k) {
         float w = W[(size_t)c * D + k];
         if (BF16) w = ceeg_bf16_to_f32(ceeg_f32_to_bf16(w));
         e = __fmaf_rn(w, w, e);
@@ -1191,13 +1208,17 @@ __global__ __launch_bounds__(1024) void vq_finalize_kernel(const float* __restri
   }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
-  __shared__ double red[1024];
+  __shared__ double red[1024], red2[1024];
   for (int c = threadIdx.x; c < n_e; c += 1024) tot[c] = 0;
   __syncthreads();
   const int64_t pairs = (int64_t)nslice * n_e;
-  for (int64_t i = threadIdx.x; i < pairs; i += 1024) {
-    const uint32_t v = hpart[i];
-    if (v) atomicAdd(&tot[i % n_e], v);
+  for (int64_t i0 = threadIdx.x; i0 < pairs; i0 += 8 * 1024) {  // 8 loads in flight
+    uint32_t v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = i0 + u * 1024 < pairs ? hpart[i0 + u * 1024] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v[u]) atomicAdd(&tot[(i0 + u * 1024) % n_e], v[u]);
   }
   double e = 0.0;
   for (int i = threadIdx.x; i < nblk; i += 1024) e += (double)err_part[i];
@@ -1210,23 +1231,19 @@ __global__ __launch_bounds__(1024) void vq_finalize_kernel(const float* __restri
     ent += (double)(p * logf(p + 1e-10f));
   }
   red[threadIdx.x] = e;
+  red2[threadIdx.x] = ent;
   __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  const double sq = red[0];
-  __syncthreads();
-  red[threadIdx.x] = ent;
-  __syncthreads();
-  for (int o = 512; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+  for (int o = 512; o > 0; o >>= 1) {  // both sums down the same fixed tree
+    if ((int)threadIdx.x < o) {
+      red[threadIdx.x] += red[threadIdx.x + o];
+      red2[threadIdx.x] += red2[threadIdx.x + o];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    const double m = sq / ((double)B * (double)D);
+    const double m = red[0] / ((double)B * (double)D);
     *loss = (float)(m + (double)beta * m);
-    *ppl = (float)exp(-red[0]);
+    *ppl = (float)exp(-red2[0]);
   }
 }
 
@@ -1278,50 +1295,77 @@ __global__ __launch_bounds__(256) void vq_dz4_kernel(const float* __restrict__ z
   }
 }
 
-// scan of the per-slice histograms: off[g][c] = (rows with smaller code) + (rows with code c in slices < g);
-// also the per-code chunk table for the segmented sum.  One block.
-__global__ void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, int n_e, uint32_t* __restrict__ off,
-                               uint32_t* __restrict__ code_base /* [n_e+1] */, uint32_t* __restrict__ chunk_base /* [n_e+1] */) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  uint32_t* tot = reinterpret_cast<uint32_t*>(smem);  // [n_e]
-  for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
-    uint32_t t = 0;
+// scan of the per-slice histograms down the slices, 64 codes per workgroup and 16 slice groups per code (the one-block form of
+// this kernel took as long as the scatter it feeds): off[g][c] = rows with code c in slices < g, tot[c] = rows with code c.
+constexpr int VQ_SCAN_GROUPS = 16;
+__global__ __launch_bounds__(64 * VQ_SCAN_GROUPS) void vq_scan_kernel(const uint32_t* __restrict__ hpart, int nslice, int n_e,
+                                                                      uint32_t* __restrict__ off, uint32_t* __restrict__ tot) {
+  __shared__ uint32_t part[VQ_SCAN_GROUPS][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (nslice + VQ_SCAN_GROUPS - 1) / VQ_SCAN_GROUPS;
+  const int g_lo = q * per, g_hi = g_lo + per < nslice ? g_lo + per : nslice;
+  uint32_t t = 0;
+  if (c < n_e) {
 #pragma unroll 8
-    for (int g = 0; g < nslice; ++g) t += hpart[(size_t)g * n_e + c];
-    tot[c] = t;
+    for (int g = g_lo; g < g_hi; ++g) t += hpart[(size_t)g * n_e + c];
   }
+  part[q][cl] = t;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t run = 0, crun = 0;
-    for (int c = 0; c < n_e; ++c) {
-      code_base[c] = run;
-      chunk_base[c] = crun;
-      run += tot[c];
-      crun += (tot[c] + VQ_SEG - 1) / VQ_SEG;
-    }
-    code_base[n_e] = run;
-    chunk_base[n_e] = crun;
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < n_e; c += blockDim.x) {
-    uint32_t run = code_base[c];
-#pragma unroll 8
-    for (int g = 0; g < nslice; ++g) {
-      off[(size_t)g * n_e + c] = run;
-      run += hpart[(size_t)g * n_e + c];
+  uint32_t run = 0;
+  for (int p = 0; p < q; ++p) run += part[p][cl];
+  if (c >= n_e) return;
+  if (q == VQ_SCAN_GROUPS - 1) tot[c] = run + t;
+  for (int g0 = g_lo; g0 < g_hi; g0 += 8) {  // 8 loads in flight
+    uint32_t h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) h[u] = g0 + u < g_hi ? hpart[(size_t)(g0 + u) * n_e + c] : 0u;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (g0 + u < g_hi) off[(size_t)(g0 + u) * n_e + c] = run;
+      run += h[u];
     }
   }
 }
 
 // stable scatter: one wave per slice walks its rows in order, 64 at a time.  The lanes holding the same code find
 // each other with one ballot per code bit (no loop over the distinct codes of the batch); equal codes are ranked
-// by lane order -> sorted[] lists the rows of each code in ascending row order (deterministic).
+// by lane order -> sorted[] lists the rows of each code in ascending row order (deterministic).  Every wave first scans tot[] over
+// the codes (first row of each code = cursor base); the wave of slice 0 also writes that scan and the per-code chunk table of the
+// segmented sum for the kernels behind it.
 __global__ __launch_bounds__(64) void vq_scatter_kernel(const int64_t* __restrict__ idx, int64_t B, int n_e, int nbits, int64_t rows_per,
-                                                        const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted) {
+                                                        const uint32_t* __restrict__ off, const uint32_t* __restrict__ tot,
+                                                        uint32_t* __restrict__ sorted, uint32_t* __restrict__ code_base /* [n_e+1] */,
+                                                        uint32_t* __restrict__ chunk_base /* [n_e+1] */) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   uint32_t* cur = reinterpret_cast<uint32_t*>(smem);  // [n_e]
   const int lane = threadIdx.x;
-  for (int c = lane; c < n_e; c += 64) cur[c] = off[(size_t)blockIdx.x * n_e + c];
+  const bool first = blockIdx.x == 0;
+  uint32_t run = 0, crun = 0;
+  for (int c0 = 0; c0 < n_e; c0 += 64) {
+    const int c = c0 + lane;
+    const uint32_t t = c < n_e ? tot[c] : 0u;
+    const uint32_t ch = (t + VQ_SEG - 1) / VQ_SEG;
+    uint32_t inc = t, cinc = ch;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t a = __shfl_up(inc, o, 64), b = __shfl_up(cinc, o, 64);
+      if (lane >= o) { inc += a; cinc += b; }
+    }
+    if (c < n_e) {
+      cur[c] = run + inc - t + off[(size_t)blockIdx.x * n_e + c];
+      if (first) {
+        code_base[c] = run + inc - t;
+        chunk_base[c] = crun + cinc - ch;
+      }
+    }
+    run += __shfl(inc, 63, 64);
+    crun += __shfl(cinc, 63, 64);
+  }
+  if (first && lane == 0) {
+    code_base[n_e] = run;
+    chunk_base[n_e] = crun;
+  }
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per;
   const int64_t hi = lo + rows_per < B ? lo + rows_per : B;
@@ -1400,9 +1444,17 @@ __global__ void vq_dw_kernel(const float* __restrict__ W, const float* __restric
   const int c = blockIdx.x;
   const float coef = s_dev[0] * beta * (2.0f / ((float)B * (float)D));
   const float cnt = (float)(code_base[c + 1] - code_base[c]);
+  const uint32_t w0 = chunk_base[c], w1 = chunk_base[c + 1];
   for (int k = threadIdx.x; k < D; k += blockDim.x) {
     float sum = 0.f;
-    for (uint32_t w = chunk_base[c]; w < chunk_base[c + 1]; ++w) sum += partial[(size_t)w * D + k];
+    for (uint32_t w = w0; w < w1; w += 16) {  // 16 partials in flight, added in chunk order (a code that took many rows has many chunks)
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = w + u < w1 ? partial[(size_t)(w + u) * D + k] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (w + u < w1) sum += v[u];
+    }
     dW[(size_t)c * D + k] = coef * (cnt * W[(size_t)c * D + k] - sum);
   }
 }
@@ -1438,14 +1490,14 @@ size_t vq_fwd_layout(int64_t B, int n_e, int D, int dtype, void* ws, size_t ws_b
   const int64_t nblk = (B + 127) / 128 + 256;  // upper bound over the kernels' partial-sum slots
   CeegWs a(ws, ws_bytes);
   size_t need = ceeg_ws_part(n_ep, 4) + ceeg_ws_part((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4, 1) +
-                ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)vq_nslice(B) * n_e, 4);
+                ceeg_ws_part(nblk, 4) + ceeg_ws_part((size_t)VQ_FWD_SLICES * n_e, 4);
   const bool sc = vq_screen_shape(n_e, D, dtype);
   if (sc) need += ceeg_ws_part((size_t)n_ep * DP, 2) + ceeg_ws_part(256, 4) + ceeg_ws_part(1, 4);
   if (out) {
     out->ee = a.take<float>(n_ep);
     out->img = a.take<char>((size_t)n_ep * DP * (dtype == CEEG_BF16 ? 2 : 4) + (size_t)n_ep * 4);
     out->err_part = a.take<float>(nblk);
-    out->hpart = a.take<uint32_t>((size_t)vq_nslice(B) * n_e);
+    out->hpart = a.take<uint32_t>((size_t)VQ_FWD_SLICES * n_e);
     if (sc) {
       out->img16 = a.take<unsigned short>((size_t)n_ep * DP);
       out->err_sc = a.take<float>(256);
@@ -1597,8 +1649,8 @@ int vq_forward_run(const void* z, const float* W, int64_t B, int n_e, int D, int
   }
   CEEG_CHECK_LAUNCH();
 
-  // forward histogram: at most 128 slices (the finalize kernel reads nslice*n_e counts)
-  int64_t rows_per = (B + 127) / 128;
+  // forward histogram: at most VQ_FWD_SLICES slices (the finalize kernel reads nslice*n_e counts)
+  int64_t rows_per = (B + VQ_FWD_SLICES - 1) / VQ_FWD_SLICES;
   rows_per = rows_per < VQ_HIST_ROWS ? VQ_HIST_ROWS : (rows_per + 255) / 256 * 256;
   const int nslice = (int)((B + rows_per - 1) / rows_per);
   hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, rows_per, w.hpart);
@@ -1648,7 +1700,7 @@ extern "C" int ceeg_vq_forward_screened(const void* ws, size_t ws_bytes, int64_t
 // (it is a host-side stand-in) - the device address comes from hipGetSymbolAddress, once per device, and only that pointer
 // goes to kernels.
 namespace {
-constexpr size_t VQ_STATIC_SCRATCH_BYTES = (size_t)4 << 20;  // covers config 3 (4 Mi x 512 x 256: 2.63 MiB) in both dtypes
+constexpr size_t VQ_STATIC_SCRATCH_BYTES = (size_t)4 << 20;  // covers config 3 (4 Mi x 512 x 256: 0.63 MiB in bf16, 0.88 MiB in fp32)
 static __device__ __align__(256) unsigned char vq_static_scratch[VQ_STATIC_SCRATCH_BYTES];
 constexpr int VQ_MAX_DEVICES = 64;
 void* g_scratch_ptr[VQ_MAX_DEVICES];  // per device; written once under g_scratch_mu
@@ -1692,18 +1744,19 @@ extern "C" int ceeg_vq_forward_static(const void* z, const float* W, int64_t B, 
 // ---------------------------------------------------------------------------------------------- backward API
 namespace {
 struct VqBwdWs {
-  uint32_t *hpart, *off, *code_base, *chunk_base, *sorted;
+  uint32_t *hpart, *off, *tot, *code_base, *chunk_base, *sorted;
   float* partial;
 };
 size_t vq_bwd_layout(int64_t B, int n_e, int D, void* ws, size_t ws_bytes, VqBwdWs* out) {
   const int64_t nslice = vq_nslice(B);
   const int64_t nchunk_max = B / VQ_SEG + n_e + 1;
-  size_t need = 2 * ceeg_ws_part((size_t)nslice * n_e, 4) + 2 * ceeg_ws_part(n_e + 1, 4) + ceeg_ws_part(B, 4) +
+  size_t need = 2 * ceeg_ws_part((size_t)nslice * n_e, 4) + 3 * ceeg_ws_part(n_e + 1, 4) + ceeg_ws_part(B, 4) +
                 ceeg_ws_part((size_t)nchunk_max * D, 4);
   if (out) {
     CeegWs a(ws, ws_bytes);
     out->hpart = a.take<uint32_t>((size_t)nslice * n_e);
     out->off = a.take<uint32_t>((size_t)nslice * n_e);
+    out->tot = a.take<uint32_t>(n_e + 1);
     out->code_base = a.take<uint32_t>(n_e + 1);
     out->chunk_base = a.take<uint32_t>(n_e + 1);
     out->sorted = a.take<uint32_t>(B);
@@ -1748,11 +1801,12 @@ extern "C" int ceeg_vq_backward(const void* z, const float* W, const int64_t* id
     const int nslice = (int)vq_nslice(B);
     hipLaunchKernelGGL(vq_hist_kernel, dim3(nslice), dim3(256), (size_t)n_e * 4, st, idx, B, n_e, (int64_t)VQ_HIST_ROWS, w.hpart);
     CEEG_CHECK_LAUNCH();
-    hipLaunchKernelGGL(vq_scan_kernel, dim3(1), dim3(512), (size_t)n_e * 4, st, w.hpart, nslice, n_e, w.off, w.code_base, w.chunk_base);
+    hipLaunchKernelGGL(vq_scan_kernel, dim3((unsigned)((n_e + 63) / 64)), dim3(64 * VQ_SCAN_GROUPS), 0, st, w.hpart, nslice, n_e, w.off, w.tot);
     CEEG_CHECK_LAUNCH();
     int nbits = 0;
     while ((1 << nbits) < n_e) ++nbits;
-    hipLaunchKernelGGL(vq_scatter_kernel, dim3(nslice), dim3(64), (size_t)n_e * 4, st, idx, B, n_e, nbits, (int64_t)VQ_HIST_ROWS, w.off, w.sorted);
+    hipLaunchKernelGGL(vq_scatter_kernel, dim3(nslice), dim3(64), (size_t)n_e * 4, st, idx, B, n_e, nbits, (int64_t)VQ_HIST_ROWS, w.off, w.tot, w.sorted,
+                       w.code_base, w.chunk_base);
     CEEG_CHECK_LAUNCH();
     const int64_t nchunk_max = B / VQ_SEG + n_e + 1;
     const unsigned sblocks = (unsigned)((nchunk_max + 3) / 4);

@@ -83,7 +83,7 @@ int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, in
  * need (codebook image, code norms, per-block error partials, per-slice histograms) is a fixed array inside the library,
  * ceeg_vq_forward_static_max_bytes() = 4 MiB per GPU the library runs on, held until the process ends.  A problem whose
  * ceeg_vq_forward_ws_bytes() exceeds that (e.g. B = 4 Mi with n_e = 1024, D = 256) returns CEEG_ETOOBIG before any
- * launch; config 3 (4 Mi x 512 x 256, both dtypes: 2.63 MiB) fits.  Calls no hipMalloc/hipFree or allocating routine.
+ * launch; config 3 (4 Mi x 512 x 256, 0.63 MiB in bf16, 0.88 MiB in fp32) fits.  Calls no hipMalloc/hipFree or allocating routine.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE - serialise
  * them.  Nothing in the array has to be zero between calls (every word a kernel reads is written earlier in the same
  * call).  The one exception to "no global mutable state" above: the per-device address of the array, looked up once.

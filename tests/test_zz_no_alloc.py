@@ -62,7 +62,7 @@ def test_static_entry_point_refuses_what_does_not_fit():
     cap = L.ceeg_vq_forward_static_max_bytes()
     assert cap == 4 << 20
     assert L.ceeg_vq_forward_ws_bytes(1 << 22, 512, 256, _lib.CEEG_BF16) <= cap  # config 3 fits
-    B, n_e, D = 1 << 22, 1024, 256
+    B, n_e, D = 1 << 22, 4096, 256
     assert L.ceeg_vq_forward_ws_bytes(B, n_e, D, _lib.CEEG_F32) > cap
     d = torch.empty(16, device="cuda")  # never dereferenced: the size check comes before any launch
     p = d.data_ptr()
