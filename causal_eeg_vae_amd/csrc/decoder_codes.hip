@@ -108,7 +108,21 @@ __global__ __launch_bounds__(256) void dc_gram_kernel(const float* __restrict__ 
   const float* wa = W + (int64_t)a * ldw;
   const float* wb = W + (int64_t)b * ldw;
   float acc = 0.f;
-  for (int k = 0; k < D; k += 4) {
+  int k = 0;
+  for (; k + 32 <= D; k += 32) {  // 8 x 16 bytes of the lane's own row in flight (row a is one broadcast line); same chain
+    float4 y[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) y[u] = *reinterpret_cast<const float4*>(wb + k + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 x = *reinterpret_cast<const float4*>(wa + k + 4 * u);
+      acc = __fmaf_rn(x.x, y[u].x, acc);
+      acc = __fmaf_rn(x.y, y[u].y, acc);
+      acc = __fmaf_rn(x.z, y[u].z, acc);
+      acc = __fmaf_rn(x.w, y[u].w, acc);
+    }
+  }
+  for (; k < D; k += 4) {
     const float4 x = *reinterpret_cast<const float4*>(wa + k);
     const float4 y = *reinterpret_cast<const float4*>(wb + k);
     acc = __fmaf_rn(x.x, y.x, acc);
