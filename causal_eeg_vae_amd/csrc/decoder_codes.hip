@@ -144,10 +144,11 @@ __global__ __launch_bounds__(256) void dc_code16_kernel(const int32_t* __restric
 // Wave w owns rows [64 w, 64 w + 64): the row pointers, sigma-rows and codes of all 64 arrive in one lane-parallel
 // load; group g walks rows 4 it + g, 16 entries at a time.  Static assignment: the loss partial of wave w goes to slot w,
 // so the sums do not depend on scheduling.
+template <bool NEG>  // NEG = false: positives only (the literal sampler path) - no sigma-row, no second table read, no negative terms
 __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restrict__ G, int K, const unsigned short* __restrict__ code,
                                                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
                                                            int64_t sig_a, int64_t sig_b, int64_t sig_mod, const float* __restrict__ row_add,
-                                                           uint4* __restrict__ rec, float* __restrict__ part, int no_neg) {
+                                                           uint4* __restrict__ rec, float* __restrict__ part) {
   const int lane = threadIdx.x & 63, gl = lane & 15, grp = lane >> 4;
   const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t row0 = w * 64;
@@ -159,11 +160,13 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
     if (row_add) radd = row_add[r];
     lo = rowptr[r];
     hi = rowptr[r + 1];
-    sr = (int)ceeg_block_affine(r, sig_a, sig_b, sig_mod);
-    slo = rowptr[sr];
-    shi = rowptr[sr + 1];
     kr = code[r];
-    ksr = code[sr];
+    if (NEG) {
+      sr = (int)ceeg_block_affine(r, sig_a, sig_b, sig_mod);
+      slo = rowptr[sr];
+      shi = rowptr[sr + 1];
+      ksr = code[sr];
+    }
     if (hi - lo > DC_CHUNK) hi = lo;  // hub row: dc_coef_long_kernel
   }
   const int cnt = N - row0 < 64 ? (int)(N - row0) : 64;
@@ -171,14 +174,29 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
   for (int it = 0; it * 4 < cnt; ++it) {
     const int j = it * 4 + grp;
     const int p_lo = __shfl(lo, j, 64), p_hi = __shfl(hi, j, 64);
-    const int g_sr = __shfl(sr, j, 64), g_slo = __shfl(slo, j, 64), g_shi = __shfl(shi, j, 64);
-    const int g_kr = __shfl(kr, j, 64), g_ksr = __shfl(ksr, j, 64);
+    const int g_kr = __shfl(kr, j, 64);
     const float g_add = __shfl(radd, j, 64);
+    const float* gr = G + (size_t)g_kr * K;
+    if (!NEG) {
+      for (int base = p_lo; __any(base < p_hi); base += 16) {
+        const int p = base + gl;
+        if (p < p_hi) {
+          const int kc = code[col[p]];
+          float tp, cp, tn, cn;
+          const float v = gr[kc] + g_add;
+          dc_terms(v, v, tp, cp, tn, cn);  // the negative half is dead code here
+          rec[p] = make_uint4(__float_as_uint(cp), 0u, (unsigned)g_kr, (unsigned)kc);
+          a_pos += tp;
+        }
+      }
+      continue;
+    }
+    const int g_sr = __shfl(sr, j, 64), g_slo = __shfl(slo, j, 64), g_shi = __shfl(shi, j, 64);
+    const int g_ksr = __shfl(ksr, j, 64);
     const int s_n = g_shi - g_slo;
     const bool s_short = s_n <= 16;
     int sc = -1;  // sigma-row's columns across the group's lanes (never equal to a column id when absent)
     if (p_lo < p_hi && s_short && gl < s_n) sc = col[g_slo + gl];
-    const float* gr = G + (size_t)g_kr * K;
     const float* gs = G + (size_t)g_ksr * K;
     for (int base = p_lo; __any(base < p_hi); base += 16) {
       const int p = base + gl;
@@ -196,7 +214,7 @@ __global__ __launch_bounds__(256) void dc_coef_rows_kernel(const float* __restri
       if (live) {
         float tp, cp, tn, cn;
         dc_terms(gr[kc] + g_add, gs[kc] + g_add, tp, cp, tn, cn);
-        const bool valid = !no_neg && c != g_sr && !hit;
+        const bool valid = c != g_sr && !hit;
         if (!valid) { tn = 0.f; cn = 0.f; }
         rec[p] = make_uint4(__float_as_uint(cp), __float_as_uint(cn), (unsigned)g_kr | ((unsigned)g_ksr << 16), (unsigned)kc);
         a_pos += tp;
@@ -636,8 +654,12 @@ extern "C" int ceeg_decoder_codes_fwd(const float* W, int64_t ldw, int n_e, int 
   hipLaunchKernelGGL(dc_gram_kernel, dim3((unsigned)((n_e + 255) / 256), (unsigned)n_e), dim3(256), 0, st, W, ldw, n_e, D, G);
   CEEG_CHECK_LAUNCH();
   uint4* r4 = static_cast<uint4*>(rec);
-  hipLaunchKernelGGL(dc_coef_rows_kernel, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col, N, sig_a, sig_b,
-                     sig_mod, row_add, r4, part, no_neg);
+  if (no_neg)
+    hipLaunchKernelGGL(dc_coef_rows_kernel<false>, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col, N, sig_a,
+                       sig_b, sig_mod, row_add, r4, part);
+  else
+    hipLaunchKernelGGL(dc_coef_rows_kernel<true>, dim3((unsigned)((nwave + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col, N, sig_a,
+                       sig_b, sig_mod, row_add, r4, part);
   CEEG_CHECK_LAUNCH();
   if (n_long > 0) {
     hipLaunchKernelGGL(dc_coef_long_kernel, dim3((unsigned)((n_long + 3) / 4)), dim3(256), 0, st, G, n_e, code16, rowptr, col,
