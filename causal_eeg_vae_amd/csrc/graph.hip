@@ -144,8 +144,8 @@ __global__ void neg_filter_build_kernel(const int32_t* __restrict__ rowptr, cons
   const int lane = threadIdx.x & 63;
   const int lo = rowptr[r], hi = rowptr[r + 1];
   for (int p = lo + lane; p < hi; p += 64) {
-    const uint32_t h = neg_filter_hash(col[p], (int32_t)r, bits);
-    atomicOr(&filter[h >> 5], 1u << (h & 31));  // integer OR: order-independent
+    const NegProbe pr = neg_filter_probe(col[p], (int32_t)r, bits);
+    atomicOr(&filter[pr.word], pr.mask);  // integer OR: order-independent
   }
 }
 
