@@ -180,6 +180,38 @@ def test_large_properties_and_determinism():
         np.testing.assert_allclose(g1.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-6 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("B,n_e,D,skew", [(1, 5, 8, False), (1000, 100, 32, False), (5000, 65, 16, True), (20000, 1000, 64, False),
+                                          (17 * 1024 + 3, 130, 128, True), (40000, 64, 256, True), (3000, 4096, 32, False)])
+def test_codebook_gradient_ragged_shapes_and_skew(B, n_e, D, skew):
+    """The backward chain (slice histograms -> scan over 64-code workgroups x 16 slice groups -> stable scatter -> chunk sums ->
+    codebook gradient) on shapes that leave its tiles ragged: fewer slices than slice groups, n_e not a multiple of 64, a last slice
+    of 3 rows, unused codes, and (skew) nearly every row on ONE code so that a code owns far more than 16 chunks of 256 rows.
+    dW and dz against the closed forms in fp64; two runs bit-identical."""
+    rng = np.random.default_rng(B + n_e + D)
+    W = rng.standard_normal((n_e, D)).astype(np.float32)
+    zn = rng.standard_normal((B, D)).astype(np.float32)
+    if skew:
+        keep = rng.random(B) < 0.02
+        zn = np.where(keep[:, None], zn, W[n_e // 3] + 1e-3 * zn).astype(np.float32)
+    vq = _mod(n_e, D, 0.25, W, one_hot=False)
+    grads = []
+    for _ in range(2):
+        z = torch.from_numpy(zn).cuda().requires_grad_(True)
+        loss, z_q, _, _, idx = vq(z)
+        loss.backward()
+        grads.append((vq.embedding.weight.grad.clone(), z.grad.clone(), idx.clone()))
+        vq.embedding.weight.grad = None
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+    i64 = grads[0][2][:, 0].cpu()
+    if skew:
+        assert int((i64 == n_e // 3).sum()) > 0.9 * B
+    z64, W64 = torch.from_numpy(zn).double(), torch.from_numpy(W).double()
+    dW = torch.zeros_like(W64).index_add_(0, i64, W64[i64] - z64) * (0.25 * 2.0 / (B * D))
+    dz = 2.0 / (B * D) * (z64 - W64[i64])
+    np.testing.assert_allclose(grads[0][0].cpu().double().numpy(), dW.numpy(), rtol=1e-5, atol=2e-6 * float(dW.abs().max()) + 1e-12)
+    np.testing.assert_allclose(grads[0][1].cpu().double().numpy(), dz.numpy(), rtol=1e-5, atol=1e-6 * float(dz.abs().max()) + 1e-12)
+
+
 def test_largest_codebook_forward_backward_and_argument_checks():
     """n_e = 4096 (the advertised limit): forward bit-exact vs the C oracle, both gradients vs the closed forms in fp64; one
     more code is refused; a bad dW workspace is refused BEFORE anything is launched (dz stays untouched)."""
