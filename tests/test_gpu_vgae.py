@@ -252,6 +252,53 @@ def test_full_step_uniform_negatives_vs_oracle(forms, monkeypatch):
     _check_step_against_fp64_oracle(ref, model, loss2, aux2, (x, ei, eps, neg2.to(torch.int64), torch.from_numpy(s2 >= 0)), {})
 
 
+@pytest.mark.parametrize("negatives", ["uniform", "sigma"])
+def test_full_step_vs_oracle_on_a_trained_state(negatives):
+    """The step check of test_full_step_vs_oracle / _uniform_negatives_vs_oracle, but on the state 40 optimizer steps leave behind
+    (lr 2e-2) instead of the random initialisation: codebook and encoder have moved towards each other, code use is uneven,
+    the decoder's logits have grown.  Loss, its parts and EVERY parameter gradient against the fp64 oracle loaded with the
+    trained weights."""
+    from causal_eeg_vae_amd import VGAEVQ, EventGraph, sigma_params
+    from causal_eeg_vae_amd.trainer import Trainer
+    from oracle import c_oracle, ref_torch
+    N, E, Fi, D, n_e = 3000, 48000, 32, 64, 128
+    ei_np = _graph(N, E, 11)
+    torch.manual_seed(1)
+    ref = ref_torch.RefVGAEVQ(Fi, D, n_e, 0.25)
+    with torch.no_grad():
+        ref.vector_quantization.embedding.weight.normal_(0, 0.3)
+    model = VGAEVQ(Fi, D, n_e, 0.25, seed=3, negatives=negatives).cuda()
+    model.load_state_dict(ref.state_dict())
+    x = torch.randn(N, Fi)
+    ei = torch.from_numpy(ei_np)
+    g = EventGraph(ei.cuda(), N)
+    tr = Trainer(model, lr=2e-2)
+    first = None
+    for _ in range(40):
+        l, aux_t = tr.step(x.cuda(), g)
+        first = float(l) if first is None else first
+    assert float(l) < first                                   # it did train
+    ref.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    model.zero_grad(set_to_none=True)
+    eps = torch.randn(N, D)
+    step = 77
+    if negatives == "uniform":
+        loss, aux = model(x.cuda(), g, step=step, eps=eps.cuda())
+        loss.backward()
+        rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+        s, d = c_oracle.neg_sample_uniform(rowptr, col, N, E, model.negative_seed(step))
+        np.testing.assert_array_equal(aux["neg_edge_index"].cpu().numpy(), np.stack([s, d]))
+        neg_ei, valid = torch.from_numpy(np.stack([s, d]).astype(np.int64)), None
+    else:
+        sig = sigma_params(N, 0, step)
+        loss, aux = model(x.cuda(), g, step=step, eps=eps.cuda(), sigma=sig)
+        loss.backward()
+        rowptr, col, _ = ref_torch.csr_build_np(ei_np[0], ei_np[1], N, False)
+        s, sg, v = ref_torch.sigma_negatives_np(rowptr, col, N, sig[0], sig[1])
+        neg_ei, valid = torch.from_numpy(np.stack([s, sg]).astype(np.int64)), torch.from_numpy(v)
+    _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, valid), {})
+
+
 @pytest.mark.parametrize("N,E,D,n_e,negative", [(1000, 20000, 64, 100, True), (777, 5000, 128, 512, False), (64, 0, 64, 8, True),
                                                  (130, 9000, 256, 33, True), (5, 40, 192, 576, False)])
 def test_pair_list_code_form_vs_fp64(N, E, D, n_e, negative):
