@@ -82,7 +82,7 @@ int ceeg_vq_forward(const void* z, const float* W, int64_t B, int n_e, int D, in
  * harnesses that forbid hipMalloc.  Same kernels, same results bit for bit as ceeg_vq_forward; the scratch the kernels
  * need (codebook image, code norms, per-block error partials, per-slice histograms) is a fixed array inside the library,
  * ceeg_vq_forward_static_max_bytes() = 4 MiB per GPU the library runs on, held until the process ends.  A problem whose
- * ceeg_vq_forward_ws_bytes() exceeds that (e.g. B = 4 Mi with n_e = 1024, D = 256) returns CEEG_ETOOBIG before any
+ * ceeg_vq_forward_ws_bytes() exceeds that (e.g. n_e = 4096 with D = 256 in fp32: a 4 MiB codebook image alone) returns CEEG_ETOOBIG before any
  * launch; config 3 (4 Mi x 512 x 256, 0.63 MiB in bf16, 0.88 MiB in fp32) fits.  Calls no hipMalloc/hipFree or allocating routine.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (two streams, two threads) RACE - serialise
  * them.  Nothing in the array has to be zero between calls (every word a kernel reads is written earlier in the same
