@@ -128,6 +128,40 @@ extern "C" int ceeg_bias_relu(float* y, int64_t ld, int64_t N, int F, const floa
   return CEEG_OK;
 }
 
+namespace {
+// out[n] = k-ascending fmaf chain from 0 of x[n,k]^2: a thread per row, the row's 16-byte pieces 8 at a time
+__global__ __launch_bounds__(EW_THREADS) void row_sqnorm_kernel(const float* __restrict__ x, int64_t ld, int64_t N, int F, float* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+  if (n >= N) return;
+  const float* r = x + n * ld;
+  float acc = 0.f;
+  int k = 0;
+  for (; k + 32 <= F; k += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4*>(r + k + 4 * u);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __fmaf_rn(v[u].x, v[u].x, acc); acc = __fmaf_rn(v[u].y, v[u].y, acc);
+      acc = __fmaf_rn(v[u].z, v[u].z, acc); acc = __fmaf_rn(v[u].w, v[u].w, acc);
+    }
+  }
+  for (; k < F; k += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(r + k);
+    acc = __fmaf_rn(v.x, v.x, acc); acc = __fmaf_rn(v.y, v.y, acc); acc = __fmaf_rn(v.z, v.z, acc); acc = __fmaf_rn(v.w, v.w, acc);
+  }
+  out[n] = acc;
+}
+}  // namespace
+
+extern "C" int ceeg_row_sqnorm(const float* x, int64_t ld, int64_t N, int F, float* out, void* stream) {
+  if (!x || !out || N <= 0 || F < 4 || (F % 4) != 0 || ld < F || (ld % 4) != 0 || !ceeg_aligned(x, 16)) return CEEG_EINVAL;
+  hipLaunchKernelGGL(row_sqnorm_kernel, dim3((unsigned)((N + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), x,
+                     ld, N, F, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
 extern "C" size_t ceeg_colsum_ws_bytes(int64_t N, int F) {
   if (N <= 0 || F <= 0) return 0;
   return ceeg_ws_part((size_t)EW_MAX_BLOCKS * F, 4);

@@ -1117,7 +1117,13 @@ class _FusedDecoder(torch.autograd.Function):
             row_add = None
             if cond_rows is not None:
                 ctx.cond = cond_rows.detach().contiguous()
-                row_add = (ctx.cond * ctx.cond).sum(dim=1).contiguous()  # |c_graph(r)|^2: the condition's share of every dot of row r
+                # |c_graph(r)|^2: the condition's share of every dot of row r
+                if ctx.cond.shape[1] % 4 == 0 and ctx.cond.dtype == torch.float32 and ctx.cond.data_ptr() % 16 == 0:
+                    row_add = torch.empty(ctx.cond.shape[0], dtype=torch.float32, device=z.device)
+                    _lib.check(L.ceeg_row_sqnorm(ctx.cond.data_ptr(), ctx.cond.stride(0), ctx.cond.shape[0], ctx.cond.shape[1],
+                                                 row_add.data_ptr(), _lib.stream()), "ceeg_row_sqnorm")
+                else:
+                    row_add = (ctx.cond * ctx.cond).sum(dim=1).contiguous()
             ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, src.shape[0], D, 0 if li is None else li.shape[0], 0), z.device)
             with _lib.timed("decoder_fwd"):
                 _lib.check(L.ceeg_decoder_codes_fwd(src.data_ptr(), src.stride(0), src.shape[0], D, sidx.data_ptr(), p.rowptr.data_ptr(),

@@ -409,7 +409,10 @@ int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const in
  *   ceeg_bias_relu       : y[n,:] = act(y[n,:] + bias) in place; bias may be NULL, relu != 0 applies max(.,0)
  *   ceeg_relu_bwd_colsum : gm = g * (y > 0) (gm may alias g) and colsum[f] = sum_n gm[n,f], one pass
  *   ceeg_colsum          : colsum[f] = sum_n g[n,f]   (deterministic: fixed-order block partials, fp64 finish)
- * y, g: [N, ld] fp32 row-major, F % 4 == 0, F <= 1024, ld % 4 == 0, 16-byte aligned. */
+ *   ceeg_row_sqnorm      : out[n] = sum_k x[n,k]^2 (k-ascending fmaf chain): |c_graph(n)|^2, the condition's share of every dot product
+ *                          of row n when the decoder runs on cat((latent, condition)) (scripts/models.py:259) in code form
+ * y, g, x: [N, ld] fp32 row-major, F % 4 == 0, F <= 1024, ld % 4 == 0, 16-byte aligned. */
+int ceeg_row_sqnorm(const float* x, int64_t ld, int64_t N, int F, float* out, void* stream);
 int ceeg_bias_relu(float* y, int64_t ld, int64_t N, int F, const float* bias, int relu, void* stream);
 size_t ceeg_colsum_ws_bytes(int64_t N, int F);
 int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F,

@@ -229,6 +229,25 @@ def test_bias_relu_and_column_sums(N, F, ld):
     assert float(((cs3.double() - g.double().sum(0)).abs() / (g.abs().double().sum(0) + 1e-30)).max()) < 1e-6
 
 
+@pytest.mark.parametrize("N,F,ld", [(1, 4, 4), (1000, 32, 32), (777, 36, 40), (5000, 256, 256)])
+def test_row_squared_norms(N, F, ld):
+    """ceeg_row_sqnorm against float64 torch; the k-ascending fmaf chain restated on the CPU gives the same bits."""
+    from causal_eeg_vae_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(N + F)
+    x = torch.randn(N, ld, device="cuda")
+    out = torch.empty(N, device="cuda")
+    _lib.check(L.ceeg_row_sqnorm(x.data_ptr(), ld, N, F, out.data_ptr(), _lib.stream()), "ceeg_row_sqnorm")
+    ref = x[:, :F].double().square().sum(1)
+    np.testing.assert_allclose(out.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-5)
+    xc = x[: min(N, 50), :F].cpu().numpy()
+    chain = np.zeros(xc.shape[0], dtype=np.float32)
+    for k in range(F):   # fmaf(a, a, acc) = the float64 product-sum rounded once (exact in float64 for float32 operands)
+        chain = (xc[:, k].astype(np.float64) * xc[:, k].astype(np.float64) + chain.astype(np.float64)).astype(np.float32)
+    np.testing.assert_array_equal(out[: xc.shape[0]].cpu().numpy(), chain)
+    assert L.ceeg_row_sqnorm(x.data_ptr(), ld, N, 6, out.data_ptr(), _lib.stream()) == -1   # F % 4 != 0
+
+
 def test_spmm_piece_list_equals_row_scan():
     """ceeg_spmm_csr_items (hub-row pieces from the graph's static list) == ceeg_spmm_csr (per-chunk row search), bit for
     bit, forward and transposed, with and without hub rows."""
