@@ -75,6 +75,7 @@ SIGNATURES = {
     "ceeg_decoder_codes_fwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_decoder_codes_bwd": (_c_int, [_vp, _c_i64, _c_int, _c_int, _vp, _vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_sz, _vp]),
     "ceeg_row_sqnorm": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _vp]),
+    "ceeg_concat_condition": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _c_int, _c_i64, _vp, _vp, _vp]),
     "ceeg_bias_relu": (_c_int, [_vp, _c_i64, _c_i64, _c_int, _vp, _c_int, _vp]),
     "ceeg_colsum_ws_bytes": (_c_sz, [_c_i64, _c_int]),
     "ceeg_relu_bwd_colsum": (_c_int, [_vp, _c_i64, _vp, _c_i64, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _c_sz, _vp]),

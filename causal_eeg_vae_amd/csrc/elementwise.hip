@@ -162,6 +162,40 @@ extern "C" int ceeg_row_sqnorm(const float* x, int64_t ld, int64_t N, int F, flo
   return CEEG_OK;
 }
 
+namespace {
+// out[n, :F] = x[n, :], out[n, F:F+C] = cond[batch[n], :]: one 16-byte piece per thread (cond is a few KB: cache-resident)
+__global__ __launch_bounds__(EW_THREADS) void concat_condition_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int F,
+                                                                      const float* __restrict__ cond, int C, int64_t G,
+                                                                      const int64_t* __restrict__ batch, float* __restrict__ out) {
+  const int pw = (F + C) / 4;
+  const int64_t total = N * pw;
+  for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < total; i += (int64_t)gridDim.x * EW_THREADS) {
+    const int64_t n = i / pw;
+    const int k = (int)(i - n * pw) * 4;
+    float4 v;
+    if (k < F) {
+      v = *reinterpret_cast<const float4*>(x + n * ldx + k);
+    } else {
+      int64_t g = batch[n];
+      g = g < 0 ? 0 : (g >= G ? G - 1 : g);   // checked on the host side of the collation; clamped here so that nothing faults
+      v = *reinterpret_cast<const float4*>(cond + g * C + (k - F));
+    }
+    *reinterpret_cast<float4*>(out + n * (int64_t)(F + C) + k) = v;
+  }
+}
+}  // namespace
+
+extern "C" int ceeg_concat_condition(const float* x, int64_t ldx, int64_t N, int F, const float* cond, int C, int64_t G, const int64_t* batch,
+                                     float* out, void* stream) {
+  if (!x || !cond || !batch || !out || N <= 0 || G <= 0 || F < 4 || C < 4 || (F % 4) != 0 || (C % 4) != 0 || ldx < F || (ldx % 4) != 0)
+    return CEEG_EINVAL;
+  if (!ceeg_aligned(x, 16) || !ceeg_aligned(cond, 16) || !ceeg_aligned(out, 16)) return CEEG_EINVAL;
+  hipLaunchKernelGGL(concat_condition_kernel, dim3(ew_blocks(N * ((F + C) / 4))), dim3(EW_THREADS), 0, static_cast<hipStream_t>(stream), x, ldx, N, F,
+                     cond, C, G, batch, out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
 extern "C" size_t ceeg_colsum_ws_bytes(int64_t N, int F) {
   if (N <= 0 || F <= 0) return 0;
   return ceeg_ws_part((size_t)EW_MAX_BLOCKS * F, 4);

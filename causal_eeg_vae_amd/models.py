@@ -1090,9 +1090,19 @@ class _FusedDecoder(torch.autograd.Function):
         # cond_rows [N, C]: extra decoder-input columns that are constant over every pair of a node (a per-graph condition,
         # block-diagonal batch, sigma inside the graphs): the code form folds them into a per-row addend; any other form
         # decodes the concatenation cat((z, cond_rows)) (scripts/models.py:259)
+        # cond_rows may also be (condition [G, C], batch [N]) = the rows condition[batch] without materialising them (no gradient
+        # reaches the condition through this form)
         ctx.cond_split = None
         use_codes = (table is not None and os.environ.get("CEEG_DEC_CODES", "1") == "1"
                      and L.ceeg_decoder_codes_supported(int(table.shape[0]), D) == 1)
+        cond_graphs = None
+        ctx.cond_is_tensor = torch.is_tensor(cond_rows)
+        if isinstance(cond_rows, tuple):
+            cg, cb = cond_rows
+            if use_codes and cg.dtype == torch.float32 and cg.shape[1] % 4 == 0:
+                cond_graphs, cond_rows = (cg.detach().contiguous(), cb), None
+            else:
+                cond_rows = cg.detach().index_select(0, cb)
         if cond_rows is not None and not use_codes:
             ctx.cond_split = (D, cond_rows.shape[1])
             z = torch.cat((z, cond_rows), dim=1)
@@ -1115,7 +1125,13 @@ class _FusedDecoder(torch.autograd.Function):
             ctx.items = (li, lt)
             rec = torch.empty(max(p.nnz, 1), 4, dtype=torch.int32, device=z.device)
             row_add = None
-            if cond_rows is not None:
+            if cond_graphs is not None:   # |c_graph|^2 per graph, broadcast to the rows through batch
+                cg, cb = cond_graphs
+                per_graph = torch.empty(cg.shape[0], dtype=torch.float32, device=z.device)
+                _lib.check(L.ceeg_row_sqnorm(cg.data_ptr(), cg.stride(0), cg.shape[0], cg.shape[1], per_graph.data_ptr(), _lib.stream()),
+                           "ceeg_row_sqnorm")
+                row_add = per_graph.index_select(0, cb)
+            elif cond_rows is not None:
                 ctx.cond = cond_rows.detach().contiguous()
                 # |c_graph(r)|^2: the condition's share of every dot of row r
                 if ctx.cond.shape[1] % 4 == 0 and ctx.cond.dtype == torch.float32 and ctx.cond.data_ptr() % 16 == 0:
@@ -1168,7 +1184,8 @@ class _FusedDecoder(torch.autograd.Function):
             li, lt = ctx.items
             nl, nt = (0 if li is None else li.shape[0]), (0 if lt is None else lt.shape[0])
             ws = _lib.workspace(L.ceeg_decoder_codes_ws_bytes(N, p.nnz, z.shape[0], D, nl, nt), z.device)
-            csum = torch.empty(N, dtype=torch.float32, device=z.device) if ctx.cond is not None else None
+            want_dcond = ctx.cond is not None and ctx.needs_input_grad[9]
+            csum = torch.empty(N, dtype=torch.float32, device=z.device) if want_dcond else None
             with _lib.timed("decoder_bwd"):
                 _lib.check(L.ceeg_decoder_codes_bwd(z.data_ptr(), z.stride(0), z.shape[0], D, p.rowptr.data_ptr(), p.t_rowptr.data_ptr(),
                                                     p.t_perm.data_ptr(), N, p.nnz, a, b, ainv, mod, _lib.ptr(li), nl, _lib.ptr(lt), nt,
@@ -1188,7 +1205,7 @@ class _FusedDecoder(torch.autograd.Function):
         ctx.grow = None
         if ctx.cond_split is not None:
             d0, c0 = ctx.cond_split
-            return dz[:, :d0], None, None, None, None, None, None, None, None, dz[:, d0:]
+            return dz[:, :d0], None, None, None, None, None, None, None, None, (dz[:, d0:] if ctx.cond_is_tensor else None)
         return dz, None, None, None, None, None, None, None, None, None
 
 
@@ -1376,6 +1393,20 @@ class ConditionalVGAEVQ(nn.Module):
         self.latent, self.cond_channels, self.seed = latent, cond_channels, int(seed)
 
     @staticmethod
+    def _concat_condition(x, condition, batch, cn):
+        """cat((x, c[batch]), dim=1): one pass (ceeg_concat_condition) when nothing in it carries a gradient, else torch.cat."""
+        F, C = x.shape[1], condition.shape[1]
+        if (x.is_cuda and not x.requires_grad and not condition.requires_grad and x.dtype == torch.float32 and condition.dtype == torch.float32
+                and batch.dtype == torch.int64 and F % 4 == 0 and C % 4 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0
+                and x.data_ptr() % 16 == 0):
+            cond = condition.contiguous()
+            out = torch.empty(x.shape[0], F + C, dtype=torch.float32, device=x.device)
+            _lib.check(_lib.lib().ceeg_concat_condition(x.data_ptr(), x.stride(0), x.shape[0], F, cond.data_ptr(), C, cond.shape[0],
+                                                        batch.contiguous().data_ptr(), out.data_ptr(), _lib.stream()), "ceeg_concat_condition")
+            return out
+        return torch.cat((x, condition.index_select(0, batch) if cn is None else cn), dim=1)
+
+    @staticmethod
     def _intra_graph(graph, batch, mod):
         """True when `batch` is the block layout of equal-sized graphs (node n in graph n // mod) and no edge crosses
         graphs - checked once per graph object (graph-construction work, one host sync)."""
@@ -1397,10 +1428,11 @@ class ConditionalVGAEVQ(nn.Module):
         N = x.shape[0]
         if batch.shape[0] != N or condition.shape[1] != self.cond_channels:
             raise ValueError("batch must hold one graph id per node and condition must be [num_graphs, cond_channels]")
-        cn = condition.index_select(0, batch)  # c[batch]
+        # c[batch] is only materialised where a gradient has to reach the condition (or a kernel wants the rows)
+        cn = condition.index_select(0, batch) if condition.requires_grad else None
         seed = (self.seed * 0x9E3779B1 + step) & (2**63 - 1)
-        ml, z, kl, vq_loss, z_q, ppl, idx = self.encoder.encode_reparam_vq(torch.cat((x, cn), dim=1), graph, eps, seed, self.training,
-                                                                          self.vector_quantization)
+        xc = self._concat_condition(x, condition, batch, cn)
+        ml, z, kl, vq_loss, z_q, ppl, idx = self.encoder.encode_reparam_vq(xc, graph, eps, seed, self.training, self.vector_quantization)
         mod = N if nodes_per_graph is None else int(nodes_per_graph)
         if N % mod:
             raise ValueError("nodes_per_graph must divide the number of nodes of the batch")
@@ -1409,8 +1441,9 @@ class ConditionalVGAEVQ(nn.Module):
             # every positive and negative pair joins two nodes of ONE graph: the condition's share of a dot product is
             # |c_graph|^2, so the decoder runs in code form on z_q with cn as constant extra columns
             rec, sums = _FusedDecoder.apply(z_q, graph, a, b, ainv, True, mod, self.vector_quantization.embedding.weight,
-                                            idx.view(-1).to(torch.int32), cn)
+                                            idx.view(-1).to(torch.int32), (condition, batch) if cn is None else cn)
         else:
+            cn = condition.index_select(0, batch) if cn is None else cn
             rec, sums = _FusedDecoder.apply(torch.cat((z_q, cn), dim=1), graph, a, b, ainv, True, mod)
         loss = _loss_sum(rec, kl, vq_loss, N)
         return loss, dict(rec=rec, kl=kl, vq=vq_loss, ppl=ppl, idx=idx, z=z, ml=ml, dec_sums=sums)

@@ -413,6 +413,11 @@ int ceeg_decoder_codes_bwd(const float* W, int64_t ldw, int n_e, int D, const in
  *                          of row n when the decoder runs on cat((latent, condition)) (scripts/models.py:259) in code form
  * y, g, x: [N, ld] fp32 row-major, F % 4 == 0, F <= 1024, ld % 4 == 0, 16-byte aligned. */
 int ceeg_row_sqnorm(const float* x, int64_t ld, int64_t N, int F, float* out, void* stream);
+/* cat((x, condition[batch]), dim=1) in one pass (scripts/models.py:162 `torch.cat((x, condition))` with the per-graph condition
+ * broadcast to the nodes through the collated `batch` vector, scripts/models.py:121-122): out [N, F + C] contiguous,
+ * cond [G, C] contiguous, batch [N] int64 graph ids (ids outside [0, G) are clamped), F % 4 == 0, C % 4 == 0. */
+int ceeg_concat_condition(const float* x, int64_t ldx, int64_t N, int F, const float* cond, int C, int64_t G, const int64_t* batch,
+                          float* out, void* stream);
 int ceeg_bias_relu(float* y, int64_t ld, int64_t N, int F, const float* bias, int relu, void* stream);
 size_t ceeg_colsum_ws_bytes(int64_t N, int F);
 int ceeg_relu_bwd_colsum(const float* g, int64_t ldg, const float* y, int64_t ldy, float* gm, int64_t ldm, int64_t N, int F,

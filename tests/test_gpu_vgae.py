@@ -370,6 +370,41 @@ def test_conditional_batched_step_vs_oracle(per_graph, D, n_e):
     _check_step_against_fp64_oracle(ref, model, loss, aux, (x, ei, eps, neg_ei, torch.from_numpy(valid)), dict(batch=batch, condition=cond))
 
 
+@pytest.mark.parametrize("per_graph", [True, False])
+def test_conditional_step_without_materialised_condition_rows(per_graph):
+    """A condition that carries no gradient never becomes an [N, C] tensor: cat((x, c[batch])) is one pass (ceeg_concat_condition) and
+    the decoder's per-row addend is |c_graph|^2 gathered through batch.  Same loss and same parameter gradients, bit for bit, as the
+    form that materialises c[batch] (taken when the condition requires a gradient); the kernel alone equals torch.cat."""
+    from causal_eeg_vae_amd import ConditionalVGAEVQ, EventGraph, _lib
+    from causal_eeg_vae_amd.synth import collate_graphs
+    G, n, e, Fi, C, D, n_e = 6, 400, 5000, 28, 4, 64, 100
+    eis = [torch.from_numpy(_graph(n, e, 30 + g)) for g in range(G)]
+    ei, batch, N = collate_graphs(eis, [n] * G)
+    torch.manual_seed(2)
+    model = ConditionalVGAEVQ(Fi, C, D, n_e, 0.25).cuda()
+    x, cond = torch.randn(N, Fi, device="cuda"), torch.randn(G, C, device="cuda")
+    g = EventGraph(ei.cuda(), N)
+    b = batch.cuda()
+    outs = []
+    for with_grad in (False, True):
+        model.zero_grad(set_to_none=True)
+        c = cond.clone().requires_grad_(with_grad)
+        loss, aux = model(x, g, b, c, step=3, nodes_per_graph=n if per_graph else None)
+        loss.backward()
+        outs.append((loss.detach().clone(), aux["idx"].clone(), [p.grad.clone() for p in model.parameters()]))
+        if with_grad:
+            assert c.grad is not None and bool(torch.isfinite(c.grad).all())
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for p0, p1 in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(p0, p1)
+    out = torch.empty(N, Fi + C, device="cuda")
+    L = _lib.lib()
+    _lib.check(L.ceeg_concat_condition(x.data_ptr(), x.stride(0), N, Fi, cond.data_ptr(), C, G, b.data_ptr(), out.data_ptr(), _lib.stream()),
+               "ceeg_concat_condition")
+    assert torch.equal(out, torch.cat((x, cond[b]), dim=1))
+    assert L.ceeg_concat_condition(x.data_ptr(), x.stride(0), N, Fi, cond.data_ptr(), 3, G, b.data_ptr(), out.data_ptr(), _lib.stream()) == -1
+
+
 @pytest.mark.parametrize("N,E,D,n_e", [(3000, 50000, 128, 512), (1000, 30000, 32, 16)])
 def test_fused_decoder_codebook_indexed_equals_expanded(N, E, D, n_e, monkeypatch):
     """Quantised latent passed as (codebook, int32 code per node): same loss, counts and gradient - bit for bit - as
