@@ -435,12 +435,18 @@ __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __re
                                                              int32_t* __restrict__ o_rowptr, int32_t* __restrict__ o_col,
                                                              int32_t* __restrict__ o_perm) {
   const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
-  if (r >= N) return;
+  const bool valid = r < N;
   const int l = threadIdx.x & 15;
-  const int lo = rowptr[r], hi = rowptr[r + 1];
-  const int s0 = loops_scan[r], nl = loops_scan[r + 1] - s0, a = lt[r];
+  int lo = 0, hi = 0, s0 = 0, nl = 0, a = 0;
+  if (valid) {
+    lo = rowptr[r];
+    hi = rowptr[r + 1];
+    s0 = loops_scan[r];
+    nl = loops_scan[r + 1] - s0;
+    a = lt[r];
+  }
   const int base = lo - s0 + (int)r;
-  if (l == 0) {
+  if (valid && l == 0) {
     o_rowptr[r] = base;
     if (r == N - 1) o_rowptr[N] = hi - loops_scan[N] + (int)N;
     o_col[base + a] = (int32_t)r;
@@ -451,19 +457,32 @@ __global__ __launch_bounds__(256) void csr_loops_fill_kernel(const int32_t* __re
       info[r] = make_int2(base - lo, 1 - nl);  // what the transposed side needs of this row, in one 8-byte read per entry
     }
   }
-  for (int p = lo + l; p < hi; p += 16) {
-    const int k = p - lo;
-    if (k >= a && k < a + nl) continue;  // an input self-loop
-    const int q = base + (k < a ? k : k - nl + 1);
+  auto entry = [&](int64_t rr, int p, int lo_, int a_, int nl_, int base_) {
+    const int k = p - lo_;
+    if (k >= a_ && k < a_ + nl_) return;  // an input self-loop
+    const int q = base_ + (k < a_ ? k : k - nl_ + 1);
     const int32_t c = col[p];
     o_col[q] = c;
     if constexpr (TRANSPOSED) {
-      const int fp = perm[p];                       // position in the raw forward CSR, in forward row c, whose column is r
+      const int fp = perm[p];                       // position in the raw forward CSR, in forward row c, whose column is rr
       const int2 fi = info[c];                      // (new - old start of forward row c, 1 - its dropped loops)
-      o_perm[q] = fp + fi.x + ((int32_t)r > c ? fi.y : 0);
+      o_perm[q] = fp + fi.x + ((int32_t)rr > c ? fi.y : 0);
     } else {
       o_perm[q] = perm[p];
     }
+  };
+  constexpr int LONG = 256;   // rows above this go to the whole wave below (hub rows of the transposed event graph run to thousands)
+  const bool is_long = hi - lo > LONG;
+  if (!is_long)
+    for (int p = lo + l; p < hi; p += 16) entry(r, p, lo, a, nl, base);
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    if (!__shfl((int)is_long, g * 16, 64)) continue;   // wave-uniform
+    const int glo = __shfl(lo, g * 16, 64), ghi = __shfl(hi, g * 16, 64), ga = __shfl(a, g * 16, 64), gnl = __shfl(nl, g * 16, 64);
+    const int gbase = __shfl(base, g * 16, 64);
+    const int64_t gr = r - (lane >> 4) + g;
+    for (int p = glo + lane; p < ghi; p += 64) entry(gr, p, glo, ga, gnl, gbase);
   }
 }
 }  // namespace
