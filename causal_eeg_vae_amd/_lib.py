@@ -30,6 +30,9 @@ SIGNATURES = {
     "ceeg_vq_backward_ws_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
     "ceeg_vq_backward": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_i64, _c_int, _c_int, _c_int, _c_f32, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_csr_build_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_int]),
+    "ceeg_csr_build_blocks_supported": (_c_int, [_c_i64, _c_i64]),
+    "ceeg_csr_build_blocks_ws_bytes": (_c_sz, [_c_i64, _c_i64, _c_i64]),
+    "ceeg_csr_build_blocks": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_csr_build": (_c_int, [_vp, _vp, _c_i64, _c_i64, _c_int, _vp, _vp, _vp, _vp, _vp, _c_sz, _vp]),
     "ceeg_csr_transpose_ws_bytes": (_c_sz, [_c_i64, _c_i64]),
     "ceeg_csr_transpose": (_c_int, [_vp, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_sz, _vp]),

@@ -80,7 +80,10 @@ class CollatedBatch:
         if len(sizes) == 1 and self.nodes_per_graph[0] > 0:
             n = int(self.nodes_per_graph[0])
             checks = {("intra", n): self.outside[0] == 0}
-        g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks, defer=True)
+        # every collated edge lies inside its graph's block of node ids by construction (local ids outside [0, n_graph) raise
+        # `outside` AND fail the device-side check of the block-keyed build, which then falls back to the general one)
+        blocks = (self.batch, self.ptr, max(self.nodes_per_graph)) if with_dec else None
+        g = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=with_dec, checks=checks, defer=True, blocks=blocks)
         g.batch = self.batch
         return g if defer else self.finish_graph(g)
 

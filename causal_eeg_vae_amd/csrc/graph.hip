@@ -277,6 +277,105 @@ size_t sort32_layout(int64_t M, unsigned end_bit, void* ws, size_t ws_bytes, Sor
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------- CSR of a collated batch
+// A collated (block-diagonal) edge list keeps every edge inside its graph's block of node ids, so the source fits in lb bits when it
+// is stored RELATIVE to its graph's first node: key = dst << lb | (src - node_ptr[batch[dst]]) has bits(N) + lb bits (19 + 13 for 64
+// graphs of 6250 nodes) - a 32-bit key-value sort of 8-byte pairs instead of a 64-bit one of 12-byte pairs, and one digit pass fewer.
+// The order is the (dst, src) order of ceeg_csr_build: same rowptr / col / perm, bit for bit.  An edge whose endpoints are not in one
+// block cannot be encoded: it is dropped and *outside is raised - the caller then builds with ceeg_csr_build.
+namespace {
+__global__ void csr_edge_keys_blocks_kernel(const int64_t* __restrict__ src, const int64_t* __restrict__ dst, int64_t E, int64_t N, unsigned lb,
+                                            const int64_t* __restrict__ batch, const int64_t* __restrict__ node_ptr, int64_t G,
+                                            uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ outside) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = src[e], d = dst[e];
+  uint32_t key = 0xffffffffu;
+  if (s >= 0 && s < N && d >= 0 && d < N) {
+    const int64_t g = batch[d];
+    bool ok = g >= 0 && g < G;
+    int64_t ls = 0;
+    if (ok) {
+      ls = s - node_ptr[g];
+      ok = ls >= 0 && ls < ((int64_t)1 << lb) && s < node_ptr[g + 1];
+    }
+    if (ok) key = ((uint32_t)d << lb) | (uint32_t)ls;
+    else atomicOr(outside, 1);   // integer OR: order-independent
+  }
+  keys[e] = key;
+  vals[e] = (int32_t)e;
+}
+
+__global__ void csr_finish_blocks_kernel(const uint32_t* __restrict__ keys, const int32_t* __restrict__ vals, int64_t M, int64_t N, unsigned lb,
+                                         const int64_t* __restrict__ batch, const int64_t* __restrict__ node_ptr,
+                                         int32_t* __restrict__ rowptr, int32_t* __restrict__ col, int32_t* __restrict__ perm,
+                                         int64_t* __restrict__ nnz_out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p > M) return;
+  int64_t d_cur = N, d_prev = -1;
+  if (p < M) {
+    const uint32_t k = keys[p];
+    const int64_t d = (int64_t)(k >> lb);
+    d_cur = d < N ? d : N;
+    if (d < N) {
+      col[p] = (int32_t)((int64_t)(k & ((1u << lb) - 1u)) + node_ptr[batch[d]]);
+      perm[p] = vals[p];
+    }
+  }
+  if (p > 0) {
+    const int64_t d = (int64_t)(keys[p - 1] >> lb);
+    d_prev = d < N ? d : N;
+  }
+  for (int64_t r = d_prev + 1; r <= d_cur; ++r) {
+    rowptr[r] = (int32_t)p;
+    if (r == N && nnz_out) *nnz_out = p;
+  }
+}
+
+unsigned blocks_lb(int64_t max_block_nodes) {  // bits for a local id < max_block_nodes
+  unsigned b = 1;
+  while (((int64_t)1 << b) < max_block_nodes) ++b;
+  return b;
+}
+}  // namespace
+
+extern "C" int ceeg_csr_build_blocks_supported(int64_t N, int64_t max_block_nodes) {
+  return N > 0 && N < ((int64_t)1 << 31) && max_block_nodes > 0 && key_bits(N) + blocks_lb(max_block_nodes) <= 32 ? 1 : 0;
+}
+
+extern "C" size_t ceeg_csr_build_blocks_ws_bytes(int64_t E, int64_t N, int64_t max_block_nodes) {
+  if (E < 0 || N <= 0 || max_block_nodes <= 0 || key_bits(N) + blocks_lb(max_block_nodes) > 32) return 0;   // 0: the key does not fit
+  return sort32_layout(E, key_bits(N) + blocks_lb(max_block_nodes), nullptr, 0, nullptr);
+}
+
+extern "C" int ceeg_csr_build_blocks(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, const int64_t* batch,
+                                     const int64_t* node_ptr, int64_t G, int64_t max_block_nodes, int32_t* rowptr, int32_t* col,
+                                     int32_t* perm, int64_t* nnz_out, int32_t* outside, void* ws, size_t ws_bytes, void* stream) {
+  if (E < 0 || N <= 0 || G <= 0 || max_block_nodes <= 0 || !rowptr || !batch || !node_ptr || !outside || (E > 0 && (!src || !dst || !col || !perm)))
+    return CEEG_EINVAL;
+  if (N >= ((int64_t)1 << 31) || E >= ((int64_t)1 << 31)) return CEEG_EUNSUPPORTED;
+  const unsigned nb = key_bits(N), lb = blocks_lb(max_block_nodes), end_bit = nb + lb;
+  if (end_bit > 32) return CEEG_EUNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  Sort32Ws w;
+  const size_t need = sort32_layout(E, end_bit, nullptr, 0, nullptr);
+  if ((need == 0 && E > 0) || ws_bytes < need || !ws || !ceeg_aligned(ws, 256)) return CEEG_EWORKSPACE;
+  if (sort32_layout(E, end_bit, ws, ws_bytes, &w) == 0) return CEEG_EWORKSPACE;
+  if (hipMemsetAsync(outside, 0, sizeof(int32_t), st) != hipSuccess) return CEEG_ELAUNCH;
+  if (E > 0) {
+    hipLaunchKernelGGL(csr_edge_keys_blocks_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, src, dst, E, N, lb, batch, node_ptr, G,
+                       w.keys_in, w.vals_in, outside);
+    CEEG_CHECK_LAUNCH();
+    size_t tb = w.temp_bytes;
+    if (rocprim::radix_sort_pairs(w.temp, tb, w.keys_in, w.keys_out, w.vals_in, w.vals_out, (size_t)E, 0u, end_bit, st, false) != hipSuccess)
+      return CEEG_ELAUNCH;
+  }
+  hipLaunchKernelGGL(csr_finish_blocks_kernel, dim3((unsigned)((E + 1 + 255) / 256)), dim3(256), 0, st, w.keys_out, w.vals_out, E, N, lb, batch,
+                     node_ptr, rowptr, col, perm, nnz_out);
+  CEEG_CHECK_LAUNCH();
+  return CEEG_OK;
+}
+
 extern "C" size_t ceeg_csr_transpose_ws_bytes(int64_t nnz, int64_t N) {
   if (nnz < 0 || N <= 0) return 0;
   return sort32_layout(nnz, key_bits(N), nullptr, 0, nullptr);

@@ -35,7 +35,11 @@ class CsrPair:
     counts) arrives in ONE small device record read once by `finalize()`.  `defer=True` leaves that read to the caller, so that
     several structures (EventGraph's two pairs, a collation's layout check) share a single host synchronisation."""
 
-    def __init__(self, edge_index, num_nodes, self_loops, defer=False, raw=None):
+    def __init__(self, edge_index, num_nodes, self_loops, defer=False, raw=None, blocks=None):
+        """blocks = (batch [N] int64, node_ptr [G+1] int64, largest graph): the edge list is a collated batch (every edge inside its
+        graph's block of node ids) - the raw-edge CSR is then sorted on 32-bit keys that hold the source relative to its graph
+        (ceeg_csr_build_blocks).  `blocks_ok` (0-d bool tensor on the device, None without blocks) says whether the promise held; if
+        not, the structure lacks the offending edges and must be rebuilt without `blocks`."""
         _lib.require_cuda(edge_index)
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -45,6 +49,7 @@ class CsrPair:
         cap = max(E + (N if self_loops else 0), 1)
         self.num_nodes, self.self_loops = N, bool(self_loops)
         self._cap = cap
+        self.blocks_ok = None
         self.rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
         self.col = torch.empty(cap, dtype=torch.int32, device=dev)
         self.perm = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -63,10 +68,21 @@ class CsrPair:
                                                  self.t_perm.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()), "ceeg_csr_add_self_loops")
         else:
             ei = edge_index.to(torch.int64).contiguous()
-            ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
-            _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
-                                        self.col.data_ptr(), self.perm.data_ptr(), None, ws.data_ptr(), ws.numel(),
-                                        _lib.stream()), "ceeg_csr_build")
+            if (blocks is not None and not self_loops and E > 0 and os.environ.get("CEEG_CSR_BLOCKS", "1") == "1"
+                    and L.ceeg_csr_build_blocks_supported(N, int(blocks[2])) == 1):
+                b_batch, b_ptr, b_max = blocks
+                flag = torch.empty(1, dtype=torch.int32, device=dev)
+                ws = _lib.workspace(L.ceeg_csr_build_blocks_ws_bytes(E, N, int(b_max)), dev)
+                _lib.check(L.ceeg_csr_build_blocks(ei[0].data_ptr(), ei[1].data_ptr(), E, N, b_batch.data_ptr(), b_ptr.data_ptr(),
+                                                   b_ptr.shape[0] - 1, int(b_max), self.rowptr.data_ptr(), self.col.data_ptr(),
+                                                   self.perm.data_ptr(), None, flag.data_ptr(), ws.data_ptr(), ws.numel(), _lib.stream()),
+                           "ceeg_csr_build_blocks")
+                self.blocks_ok = flag[0] == 0
+            else:
+                ws = _lib.workspace(L.ceeg_csr_build_ws_bytes(E, N, int(self_loops)), dev)
+                _lib.check(L.ceeg_csr_build(ei[0].data_ptr(), ei[1].data_ptr(), E, N, int(self_loops), self.rowptr.data_ptr(),
+                                            self.col.data_ptr(), self.perm.data_ptr(), None, ws.data_ptr(), ws.numel(),
+                                            _lib.stream()), "ceeg_csr_build")
             # the transpose runs on the CAPACITY: the true entry count (input self-loops dropped, out-of-range ids skipped) stays
             # on the device until finalize()
             ws = _lib.workspace(L.ceeg_csr_transpose_ws_bytes(cap, N), dev)
@@ -144,11 +160,16 @@ class EventGraph:
     synchronisation - what a loop that sees a new minibatch every step (scripts/run.py:310-326) wants.  Without them the decoder
     pair is built on first use (a second synchronisation)."""
 
-    def __init__(self, edge_index, num_nodes, edge_weight=None, with_dec=False, checks=None, defer=False):
+    def __init__(self, edge_index, num_nodes, edge_weight=None, with_dec=False, checks=None, defer=False, blocks=None):
+        """blocks: see CsrPair - a collation's promise that every edge stays inside its graph; checked on the device, and a broken
+        promise only costs a second construction in finish()."""
         self.edge_index = edge_index
         self.num_nodes = int(num_nodes)
         self.num_edges = int(edge_index.shape[1])
-        self._dec = CsrPair(edge_index, num_nodes, self_loops=False, defer=True) if with_dec else None
+        self._dec = CsrPair(edge_index, num_nodes, self_loops=False, defer=True, blocks=blocks) if with_dec else None
+        if self._dec is not None and self._dec.blocks_ok is not None:
+            checks = dict(checks or {})
+            checks[("csr_blocks",)] = self._dec.blocks_ok
         derive = with_dec and os.environ.get("CEEG_GCN_FROM_RAW", "1") == "1"
         self.gcn = CsrPair(edge_index, num_nodes, self_loops=True, defer=True, raw=self._dec if derive else None)
         names = list(checks or {})
@@ -179,6 +200,12 @@ class EventGraph:
         if with_dec:
             self._dec.finalize(rec[6:12])
         self.checks = {k: bool(v) for k, v in zip(names, rec[len(rec) - len(names):].tolist())} if names else {}
+        if not self.checks.pop(("csr_blocks",), True):
+            # an edge left its graph's block: the 32-bit keyed structure lacks it - build again on the general keys (synchronously)
+            other = EventGraph(self.edge_index, self.num_nodes, edge_weight, with_dec=True)
+            other.checks.update(self.checks)
+            self.__dict__.update(other.__dict__)
+            return self
         L = _lib.lib()
         dev = self.edge_index.device
         ew = None if edge_weight is None else edge_weight.to(torch.float32).contiguous()

@@ -135,6 +135,17 @@ size_t ceeg_csr_build_ws_bytes(int64_t E, int64_t N, int self_loops);
 int ceeg_csr_build(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, int self_loops,
                    int32_t* rowptr, int32_t* col, int32_t* perm, int64_t* nnz_out,
                    void* ws, size_t ws_bytes, void* stream);
+/* ceeg_csr_build for a COLLATED batch (PyG Batch.from_data_list as scripts/run.py:310 collates: block-diagonal, every edge inside its
+ * graph's block of node ids): batch [N] int64 = graph of every node, node_ptr [G+1] int64 = first node of every graph,
+ * max_block_nodes >= the largest graph.  The sort key holds the source relative to its graph, bits(N) + bits(max_block_nodes) <= 32
+ * (ceeg_csr_build_blocks_supported says 1): a 32-bit key-value sort instead of a 64-bit one.  Same rowptr / col / perm as
+ * ceeg_csr_build(self_loops = 0), bit for bit.  *outside (device int32) is set to 1 when an edge is NOT inside one graph's block - such an
+ * edge is dropped and the caller must build with ceeg_csr_build instead - else 0. */
+int ceeg_csr_build_blocks_supported(int64_t N, int64_t max_block_nodes);
+size_t ceeg_csr_build_blocks_ws_bytes(int64_t E, int64_t N, int64_t max_block_nodes);
+int ceeg_csr_build_blocks(const int64_t* src, const int64_t* dst, int64_t E, int64_t N, const int64_t* batch, const int64_t* node_ptr,
+                          int64_t G, int64_t max_block_nodes, int32_t* rowptr, int32_t* col, int32_t* perm, int64_t* nnz_out,
+                          int32_t* outside, void* ws, size_t ws_bytes, void* stream);
 size_t ceeg_csr_transpose_ws_bytes(int64_t nnz, int64_t N);
 int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int64_t nnz, int64_t N,
                        int32_t* t_rowptr, int32_t* t_col, int32_t* t_perm,

@@ -248,6 +248,48 @@ def test_row_squared_norms(N, F, ld):
     assert L.ceeg_row_sqnorm(x.data_ptr(), ld, N, 6, out.data_ptr(), _lib.stream()) == -1   # F % 4 != 0
 
 
+@pytest.mark.parametrize("sizes", [[500] * 6, [1, 7, 300, 64, 1000], [8192, 10]])
+def test_collated_batch_block_keyed_build_equals_general(sizes, monkeypatch):
+    """CollatedBatch.event_graph sorts its raw-edge CSR on 32-bit keys that hold the source relative to its graph
+    (ceeg_csr_build_blocks); CEEG_CSR_BLOCKS=0 keeps the general 64-bit keys: every array of both CSR pairs equal, for equal and
+    ragged graph sizes, duplicate edges and self-loops included.  A list with a local id outside its graph (an edge that leaves its
+    block) fails the device-side check and the construction falls back: again the general build's arrays."""
+    from causal_eeg_vae_amd import _lib
+    from causal_eeg_vae_amd.collate import CollatedBatch
+    rng = np.random.default_rng(len(sizes))
+    eis = []
+    for n in sizes:
+        e = 0 if n == 1 else int(rng.integers(1, 12 * n))
+        ei = rng.integers(0, n, size=(2, e))
+        if e > 4:
+            ei[:, 1] = ei[:, 0]          # a duplicate edge
+            ei[1, 2] = ei[0, 2]          # a self-loop
+        eis.append(torch.from_numpy(ei).cuda())
+
+    def arrays(g):
+        out = []
+        for p in (g.dec, g.gcn):
+            out += [p.rowptr, p.col, p.perm, p.t_rowptr, p.t_col, p.t_perm]
+        return out + [g.gcn_val, g.gcn_tval, g.dinv]
+
+    for bad in (False, True):
+        lists = [e.clone() for e in eis]
+        if bad:
+            k = max(range(len(sizes)), key=lambda i: lists[i].shape[1])
+            lists[k][0, 0] = sizes[k] + 3          # not a local id of graph k: lands in the next graph's block (or past the batch)
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("CEEG_CSR_BLOCKS", flag)
+            cb = CollatedBatch(lists, sizes)
+            g = cb.event_graph()
+            got[flag] = arrays(g)
+            assert bool(cb.outside[0] != 0) == bad
+        for a, b in zip(got["1"], got["0"]):
+            assert torch.equal(a, b)
+    L = _lib.lib()
+    assert L.ceeg_csr_build_blocks_supported(400_000, 6250) == 1 and L.ceeg_csr_build_blocks_supported(1 << 20, 1 << 13) == 0
+
+
 def test_spmm_piece_list_equals_row_scan():
     """ceeg_spmm_csr_items (hub-row pieces from the graph's static list) == ceeg_spmm_csr (per-chunk row search), bit for
     bit, forward and transposed, with and without hub rows."""
