@@ -73,11 +73,11 @@ __global__ void csr_finish_kernel(const uint64_t* __restrict__ keys, const int32
 // at N = 1 M) instead of 64-bit (col, row) keys over 2 nb.  rowid[p] = row of entry p; positions no row covers keep key 0xffffffff.
 __global__ void csr_transpose_keys32_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t N,
                                             uint32_t* __restrict__ keys, int32_t* __restrict__ vals, int32_t* __restrict__ rowid) {
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);  // one wave per row
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);  // 16 lanes per row (the mean row of an event graph)
   if (r >= N) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 15;
   const int lo = rowptr[r], hi = rowptr[r + 1];
-  for (int p = lo + lane; p < hi; p += 64) {
+  for (int p = lo + lane; p < hi; p += 16) {
     keys[p] = (uint32_t)col[p];
     vals[p] = p;
     rowid[p] = (int32_t)r;
@@ -125,12 +125,12 @@ __global__ void gcn_deg_kernel(const int32_t* __restrict__ rowptr, const int32_t
 
 __global__ void gcn_val_kernel(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, const int32_t* __restrict__ perm,
                                const float* __restrict__ ew, const float* __restrict__ dinv, int64_t N, float* __restrict__ val) {
-  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);  // 16 lanes per row
   if (r >= N) return;
-  const int lane = threadIdx.x & 63;
+  const int lane = threadIdx.x & 15;
   const int lo = rowptr[r], hi = rowptr[r + 1];
   const float dr = dinv[r];
-  for (int p = lo + lane; p < hi; p += 64) {
+  for (int p = lo + lane; p < hi; p += 16) {
     float w = 1.0f;
     if (ew) { const int e = perm[p]; w = e >= 0 ? ew[e] : 1.0f; }
     val[p] = dinv[col[p]] * w * dr;
@@ -395,7 +395,7 @@ extern "C" int ceeg_csr_transpose(const int32_t* rowptr, const int32_t* col, int
   // `nnz` may be a CAPACITY (>= rowptr[N], the true count, which then never has to cross to the host): positions the rows do
   // not cover keep the all-ones key, sort behind every entry and are ignored by the finish kernel
   if (nnz > 0 && hipMemsetAsync(w.keys_in, 0xff, (size_t)nnz * 4, st) != hipSuccess) return CEEG_ELAUNCH;
-  hipLaunchKernelGGL(csr_transpose_keys32_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in, w.rowid);
+  hipLaunchKernelGGL(csr_transpose_keys32_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, rowptr, col, N, w.keys_in, w.vals_in, w.rowid);
   CEEG_CHECK_LAUNCH();
   size_t tb = w.temp_bytes;
   if (nnz > 0) {
@@ -651,7 +651,7 @@ extern "C" int ceeg_gcn_norm(const int32_t* rowptr, const int32_t* col, const in
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(gcn_deg_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, rowptr, perm, ew, N, deg_inv_sqrt);
   CEEG_CHECK_LAUNCH();
-  hipLaunchKernelGGL(gcn_val_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, rowptr, col, perm, ew, deg_inv_sqrt, N, val);
+  hipLaunchKernelGGL(gcn_val_kernel, dim3((unsigned)((N + 15) / 16)), dim3(256), 0, st, rowptr, col, perm, ew, deg_inv_sqrt, N, val);
   CEEG_CHECK_LAUNCH();
   return CEEG_OK;
 }
