@@ -187,7 +187,7 @@ def run_cvgae(args, dev, steps, warmup, rank=0, world=1, barrier=None):
                                     f"latent {args.latent}(+{C} decoding), {args.codes} codes, per-graph 1:1 permutation-structured negatives, Adam")
 
 
-def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=None, prefetch=False):
+def run_cvgae_stream(args, dev, steps, warmup, fresh, rank=0, world=1, barrier=None, prefetch=True):
     """configs[3] as the minibatch STREAM the reference's loader produces (scripts/run.py:310-326: a new batch every step):
     `fresh` pre-generated minibatches (per-graph edge lists, features and conditions resident in HBM) are visited round-robin and
     EVERYTHING per-batch happens inside the timed region - device collation (CollatedBatch), both CSR pairs with their
@@ -635,13 +635,15 @@ def main():
             leg("cvgae", leg_cvgae)
 
             def leg_stream():
-                el_s, build_ms, loss_s, wl_s = run_cvgae_stream(args, dev, 20, 3, 4)
-                line["cvgae_stream"] = {"ms_per_step": el_s / 20 * 1e3, "graph_build_ms": build_ms, "edges_per_s": args.graphs * args.edges_per_graph / (el_s / 20),
-                                        "steps": 20, "workload": wl_s, "loss": loss_s}
+                # the loader's default (MinibatchStream(prefetch=True): construction two minibatches ahead on a side stream) is the
+                # figure; the plain loop on the step's own stream is timed beside it - its graph_build_ms is the construction alone
+                el_p, _, loss_p, wl_p = run_cvgae_stream(args, dev, 20, 3, 4, prefetch=True)
+                el_s, build_ms, _, _ = run_cvgae_stream(args, dev, 20, 3, 4, prefetch=False)
+                line["cvgae_stream"] = {"ms_per_step": el_p / 20 * 1e3, "edges_per_s": args.graphs * args.edges_per_graph / (el_p / 20),
+                                        "serial_loop_ms_per_step": el_s / 20 * 1e3, "graph_build_ms": build_ms,
+                                        "steps": 20, "workload": wl_p, "loss": loss_p}
 
             leg("cvgae_stream", leg_stream)
-            # the side-stream loader (MinibatchStream, --prefetch) is measured by an explicit run
-            # (`--workload cvgae --fresh-batches 4 --prefetch`, profiles/r03_bench_cvgae_stream_prefetch.json), not in the default line
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(args)

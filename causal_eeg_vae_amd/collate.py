@@ -120,7 +120,7 @@ class MinibatchStream:
     (scripts/run.py:87-98,310) for minibatches whose per-graph edge lists are resident on the device.
 
     `minibatches` yields (edge_indices, nodes_per_graph) or (edge_indices, nodes_per_graph, follow) (+ an optional 4th item,
-    the collated edge weights).  prefetch=False (default) is the plain loop on the current stream.  With prefetch=True the
+    the collated edge weights).  prefetch=False is the plain loop on the current stream.  With prefetch=True (the default) the
     construction runs on a SIDE stream, `depth` minibatches ahead
     of the caller's optimizer steps on the current stream, in two halves: `begin` (collation, both CSR pairs, transposes, piece
     lists, layout check, the record's asynchronous copy to pinned host memory - no host wait) when a minibatch enters the
@@ -133,9 +133,10 @@ class MinibatchStream:
       * the iterator keeps the minibatch it handed out last referenced until the next one has been handed out.
     The inputs (edge lists, follow tensors) must be complete on the current stream when iteration starts.  Which one is faster is a
     measurement: the overlap hides the host's one read and the launch gaps of the construction but its sorts compete with the
-    step for the memory system (config 4 on an MI355X: 6.88 ms/step against 6.79 for the plain loop).  `build_events` (timing=True): (start, end) event pairs, two per minibatch."""
+    step for the memory system (config 4 on an MI355X: 5.76 ms/step against 6.06 for the plain loop once the construction was down
+    to 1.25 ms per minibatch; 6.88 against 6.79 when it took 1.5 ms - DESIGN.md section 4.7).  `build_events` (timing=True): (start, end) event pairs, two per minibatch."""
 
-    def __init__(self, minibatches, with_dec=True, prefetch=False, depth=2, timing=False):
+    def __init__(self, minibatches, with_dec=True, prefetch=True, depth=2, timing=False):
         if depth < 1:
             raise ValueError("depth >= 1")
         self.minibatches, self.with_dec, self.prefetch, self.depth, self.timing = minibatches, bool(with_dec), bool(prefetch), int(depth), bool(timing)
