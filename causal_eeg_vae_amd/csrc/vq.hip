@@ -1187,9 +1187,16 @@ __global__ void vq_hist_kernel(const int64_t* __restrict__ idx, int64_t B, int n
   __syncthreads();
   const int64_t lo = (int64_t)blockIdx.x * rows_per;
   const int64_t hi = lo + rows_per < B ? lo + rows_per : B;
-  for (int64_t b = lo + threadIdx.x; b < hi; b += blockDim.x) {
-    const int64_t k = idx[b];
-    if (k >= 0 && k < n_e) atomicAdd(&h[k], 1u);
+  for (int64_t b0 = lo + threadIdx.x; b0 < hi; b0 += 8 * (int64_t)blockDim.x) {  // 8 loads in flight
+    int64_t k[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int64_t b = b0 + u * (int64_t)blockDim.x;
+      k[u] = b < hi ? idx[b] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k[u] >= 0 && k[u] < n_e) atomicAdd(&h[k[u]], 1u);
   }
   __syncthreads();
   for (int c = threadIdx.x; c < n_e; c += blockDim.x) part[(size_t)blockIdx.x * n_e + c] = h[c];
